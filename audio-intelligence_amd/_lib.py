@@ -1,0 +1,153 @@
+"""ctypes binding of the C ABI in include/afhip.h (csrc/libafhip.so).
+
+`torch` is imported first on purpose: the library's DT_NEEDED `libamdhip64.so.7` then resolves to the HIP
+runtime PyTorch already loaded, so torch's device pointers and streams are valid inside the library.
+There is no fallback of any kind: if the library is missing, cannot be loaded, or no GPU is visible,
+`lib()` raises and every op built on it fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libafhip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
+
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldres", C.c_int),
+                ("dtype", C.c_int), ("act", C.c_int), ("res_row_mod", C.c_int),
+                ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("key_len", C.c_void_p),
+                ("B", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("n_q", C.c_int), ("n_kv", C.c_int), ("hd", C.c_int),
+                ("ld_q", C.c_int), ("ld_kv", C.c_int), ("ld_o", C.c_int),
+                ("q_batch_stride", C.c_longlong), ("kv_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
+                ("q_head_stride", C.c_longlong), ("kv_head_stride", C.c_longlong),
+                ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int)]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("n_mels", C.c_int), ("d_model", C.c_int), ("n_heads", C.c_int), ("ffn_dim", C.c_int),
+                ("n_layers", C.c_int), ("max_pos", C.c_int), ("dtype", C.c_int),
+                ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+                ("pos_emb", C.c_void_p),
+                ("ln1_w", c_void_pp), ("ln1_b", c_void_pp), ("qkv_w", c_void_pp), ("qkv_b", c_void_pp),
+                ("out_w", c_void_pp), ("out_b", c_void_pp), ("ln2_w", c_void_pp), ("ln2_b", c_void_pp),
+                ("fc1_w", c_void_pp), ("fc1_b", c_void_pp), ("fc2_w", c_void_pp), ("fc2_b", c_void_pp),
+                ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p)]
+
+
+class LlmWeights(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("n_layers", C.c_int), ("n_q", C.c_int), ("n_kv", C.c_int), ("hd", C.c_int),
+                ("inter", C.c_int), ("vocab", C.c_int), ("n_stream", C.c_int), ("rms_eps", C.c_float), ("dtype", C.c_int),
+                ("embed", C.c_void_p),
+                ("ln1_w", c_void_pp), ("qkv_w", c_void_pp), ("qkv_b", c_void_pp), ("o_w", c_void_pp),
+                ("ln2_w", c_void_pp), ("gu_w", c_void_pp), ("down_w", c_void_pp),
+                ("norm_w", C.c_void_p), ("lm_head", C.c_void_p), ("stream_emb", C.c_void_p),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int)]
+
+
+class KvCache(C.Structure):
+    _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("cap", C.c_int), ("B", C.c_int)]
+
+
+class DecodeState(C.Structure):
+    _fields_ = [("prev_token", C.c_void_p), ("out_tokens", C.c_void_p), ("finished_at", C.c_void_p),
+                ("allowed", C.c_void_p), ("n_iv", C.c_int), ("eos_id", C.c_int), ("eot_id", C.c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/afhip.h one to one (tests/test_cabi.py checks the header against this)
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "afhip_version": (_I, []),
+    "afhip_last_error": (C.c_char_p, []),
+    "afhip_log_mel_workspace_bytes": (_Z, [_I]),
+    "afhip_log_mel": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "afhip_gemm": (_I, [C.POINTER(GemmArgs), _P]),
+    "afhip_gemm_skinny": (_I, [C.POINTER(GemmArgs), _P]),
+    "afhip_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "afhip_avgpool_ln": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "afhip_rmsnorm": (_I, [_P, _P, _P, _I, _I, _F, _I, _P]),
+    "afhip_embed_sum": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "afhip_rope_kv": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "afhip_transpose_cast": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "afhip_attention": (_I, [C.POINTER(AttnArgs), _P]),
+    "afhip_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderWeights), _I]),
+    "afhip_encoder_forward": (_I, [C.POINTER(EncoderWeights), _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I]),
+    "afhip_llm_forward": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
+    "afhip_lm_head": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _P, _P, _Z, _P]),
+    "afhip_masked_argmax": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "afhip_llm_decode_step": (_I, [C.POINTER(LlmWeights), C.POINTER(KvCache), C.POINTER(DecodeState), _I, _I, _I, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class AfhipError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the C-ABI library and attach signatures. Raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise AfhipError(f"HIP library not built: {path} (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"or `make -C {os.path.dirname(path)}`); this package has no CPU fallback")
+    lib = C.CDLL(path)
+    partial = os.environ.get("AFHIP_ALLOW_PARTIAL") == "1"  # bring-up only: tolerate not-yet-built symbols
+    for name, (res, args) in SIGNATURES.items():
+        if partial and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib():
+    """The loaded library, for compute: additionally requires a visible GPU."""
+    L = load_library()
+    if not torch.cuda.is_available():
+        raise AfhipError("no HIP device visible: the AF3/UALM forward pass runs on MI355X only (no CPU fallback)")
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load_library().afhip_last_error().decode("utf-8", "replace")
+        raise AfhipError(f"afhip error {rc}: {msg}")
+
+
+def dtype_code(dt) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise AfhipError(f"unsupported dtype {dt} (float32 or bfloat16)")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

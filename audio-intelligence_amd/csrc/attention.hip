@@ -1,0 +1,279 @@
+// Flash-style attention for gfx950 (encoder: non-causal + per-clip key length; LLM prefill/decode: causal, GQA).
+// Scores never leave registers.  Orientation (cdna guide, "accumulator tile as the next MFMA's operand"):
+//   S^T[key, query] = K_tile . Q^T      (A = K rows from LDS, B = Q rows held in registers for the whole kernel)
+//   O^T[d,   query] = V^T    . P^T      (A = V^T rows from LDS, B = the S^T accumulator registers themselves)
+// so the query lives on the MFMA lane: row max / row sum are per-lane loops + one lane^32 exchange, the O rescale
+// is a per-lane scalar, and P feeds the second MFMA with no LDS round trip.  The key order inside an S^T tile is
+// permuted on the K-load side (bits 2 and 3 of the tile row swapped) so that the V^T fragment of a k-step is 8
+// consecutive keys (one 16-byte LDS read in bf16).
+// One workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 64 keys staged through LDS with
+// register prefetch.  Same template for bf16 (32x32x16 MFMA) and exact f32 (32x32x2 MFMA) via common.h mma16.
+#include "common.h"
+
+namespace {
+
+constexpr int QT = 128, KT = 64;
+
+struct AttnP {
+    const char* q;
+    const char* k;
+    const char* v;
+    char* o;
+    const int32_t* key_len;
+    int B, Tq, Tk, n_q, n_kv, hd;
+    long long ld_q, ld_kv, ld_o;
+    long long q_bs, kv_bs, o_bs;
+    long long q_hs, kv_hs;
+    int causal, q_pos0;
+    float scale_log2;
+};
+
+__device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+__device__ __forceinline__ int vswz(int row) { return ((row >> 3) ^ row) & 7; }
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+    constexpr int SZ = sizeof(T);
+    constexpr int KROWB = HD * SZ;             // bytes per K row in LDS
+    constexpr int VROWB = KT * SZ;             // bytes per V^T row in LDS
+    constexpr int KCPR = KROWB / 16;           // 16-B chunks per K row (>= 8)
+    constexpr int NLD = (KT * KROWB / 16) / 256;  // 16-B chunks per thread per operand tile
+    constexpr int EPC = 16 / SZ;               // elements per 16-B chunk
+    constexpr int DSTEPS = HD / 16, DT = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + KT * KROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int b = blockIdx.z, hq = blockIdx.y;
+    const int hkv = hq / (p.n_q / p.n_kv);
+    const int q0 = blockIdx.x * QT;
+    const int qrow = q0 + wave * 32 + fr;                 // this lane's query
+    const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+    const int qpos = p.q_pos0 + qrow;
+
+    const char* qb = p.q + ((long long)b * p.q_bs + (long long)hq * p.q_hs) * SZ;
+    const char* kb = p.k + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
+    const char* vb = p.v + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
+
+    int klen = p.Tk;
+    if (p.key_len) { const int kl = p.key_len[b]; klen = kl < klen ? kl : klen; }
+    int kend = klen;                                       // keys this workgroup must visit
+    if (p.causal) {
+        const int last = p.q_pos0 + (q0 + QT - 1 < p.Tq - 1 ? q0 + QT - 1 : p.Tq - 1) + 1;
+        kend = last < kend ? last : kend;
+    }
+    const int ntiles = (kend + KT - 1) / KT;
+
+    // ---- Q fragments (B operand), resident for the whole kernel ----
+    typename Frag8<T>::type qf[DSTEPS];
+    {
+        const T* qp = reinterpret_cast<const T*>(qb) + (long long)qrow_c * p.ld_q;
+#pragma unroll
+        for (int dc = 0; dc < DSTEPS; ++dc) qf[dc] = *reinterpret_cast<const typename Frag8<T>::type*>(qp + dc * 16 + fh * 8);
+    }
+
+    f32x16 ot[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    u32x4 rk[NLD], rv[NLD];
+    auto load_tile = [&](int t) {
+        const int k0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / KCPR, cc = c % KCPR;
+            int key = k0 + row;
+            key = key < p.Tk ? key : p.Tk - 1;
+            const long long off = ((long long)key * p.ld_kv) * SZ + cc * 16;
+            rk[i] = ld16(kb + off);
+            rv[i] = ld16(vb + off);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / KCPR, cc = c % KCPR;
+            st16(Ks + row * KROWB + ((cc ^ (row & 7)) << 4), rk[i]);
+            // transpose V chunk: element e of this chunk is V[key=row][d = cc*EPC + e] -> Vt[d][key]
+            const int kch = row / EPC, kin = row % EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int d = cc * EPC + e;
+                char* dst = Vt + d * VROWB + ((kch ^ vswz(d)) << 4) + kin * SZ;
+                if constexpr (SZ == 2) {
+                    const uint32_t wv = rv[i][e >> 1];
+                    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+                } else {
+                    *reinterpret_cast<uint32_t*>(dst) = rv[i][e];
+                }
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        if (t + 1 < ntiles) load_tile(t + 1);
+
+        // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
+        f32x16 st[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[ks][e] = 0.f;
+            const int krow = ks * 32 + swap23(fr);
+#pragma unroll
+            for (int dc = 0; dc < DSTEPS; ++dc) {
+                typename Frag8<T>::type kf;
+                if constexpr (SZ == 2) {
+                    const int ch = dc * 2 + fh;
+                    kf = *reinterpret_cast<const bf16x8*>(Ks + krow * KROWB + ((ch ^ (krow & 7)) << 4));
+                } else {
+                    const int ch = dc * 4 + fh * 2;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + ((ch ^ (krow & 7)) << 4));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + (((ch + 1) ^ (krow & 7)) << 4));
+                    kf = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
+                st[ks] = mma16(kf, qf[dc], st[ks]);
+            }
+        }
+
+        // ---- mask + online softmax (query = this lane's column) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + ks * 32 + swap23(mfma32_row(e, lane));
+                const bool ok = key < klen && (!p.causal || key <= qpos);
+                const float s = ok ? st[ks][e] * p.scale_log2 : -INFINITY;
+                st[ks][e] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_i, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_i - m_use);            // m_i = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = exp2f(st[ks][e] - m_use);
+                st[ks][e] = pv;
+                psum += pv;
+            }
+        l_i = l_i * alpha + psum;
+        m_i = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+
+        // ---- O^T += V^T . P^T ; step s covers keys [16s, 16s+16) of the tile ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            typename Frag8<T>::type pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(st[s >> 1][8 * (s & 1) + j]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int vrow = dt * 32 + fr;
+                typename Frag8<T>::type vf;
+                if constexpr (SZ == 2) {
+                    const int ch = s * 2 + fh;
+                    vf = *reinterpret_cast<const bf16x8*>(Vt + vrow * VROWB + ((ch ^ vswz(vrow)) << 4));
+                } else {
+                    const int ch = s * 4 + fh * 2;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + ((ch ^ vswz(vrow)) << 4));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + (((ch + 1) ^ vswz(vrow)) << 4));
+                    vf = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
+                ot[dt] = mma16(vf, pf, ot[dt]);
+            }
+        }
+
+        __syncthreads();
+        if (t + 1 < ntiles) store_tile();
+        __syncthreads();
+    }
+
+    // ---- normalise and write O[query, d] ----
+    const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < p.Tq) {
+        T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * fh;
+                if constexpr (SZ == 2) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (bf16)(ot[dt][4 * g + e] * inv);
+                    *reinterpret_cast<bf16x4*>(op + d) = w;
+                } else {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = ot[dt][4 * g + e] * inv;
+                    *reinterpret_cast<f32x4*>(op + d) = w;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
+    AFHIP_CHECK(a != nullptr, "afhip_attention: null args");
+    AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_attention: bad dtype %d", a->dtype);
+    AFHIP_CHECK(a->q && a->k && a->v && a->out, "afhip_attention: null tensor");
+    AFHIP_CHECK(a->B > 0 && a->Tq > 0 && a->Tk > 0 && a->n_q > 0 && a->n_kv > 0 && a->n_q % a->n_kv == 0,
+                "afhip_attention: bad shape B=%d Tq=%d Tk=%d n_q=%d n_kv=%d", a->B, a->Tq, a->Tk, a->n_q, a->n_kv);
+    AFHIP_CHECK(a->hd == 64 || a->hd == 128, "afhip_attention: head_dim %d unsupported (64 or 128)", a->hd);
+    const size_t sz = dtype_size(a->dtype);
+    AFHIP_CHECK(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 && ((uintptr_t)a->out % 16) == 0,
+                "afhip_attention: tensors must be 16-byte aligned");
+    AFHIP_CHECK((a->ld_q * sz) % 16 == 0 && (a->ld_kv * sz) % 16 == 0 && (a->ld_o * sz) % 16 == 0 &&
+                    (a->q_head_stride * sz) % 16 == 0 && (a->kv_head_stride * sz) % 16 == 0 &&
+                    (a->q_batch_stride * sz) % 16 == 0 && (a->kv_batch_stride * sz) % 16 == 0 && (a->o_batch_stride * sz) % 16 == 0,
+                "afhip_attention: strides must keep 16-byte alignment");
+    AFHIP_CHECK(a->ld_o >= a->n_q * a->hd, "afhip_attention: ld_o too small");
+    if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
+    AFHIP_CHECK(a->n_q <= 65535 && a->B <= 65535, "afhip_attention: grid too large");
+
+    AttnP p;
+    p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;
+    p.key_len = a->key_len;
+    p.B = a->B; p.Tq = a->Tq; p.Tk = a->Tk; p.n_q = a->n_q; p.n_kv = a->n_kv; p.hd = a->hd;
+    p.ld_q = a->ld_q; p.ld_kv = a->ld_kv; p.ld_o = a->ld_o;
+    p.q_bs = a->q_batch_stride; p.kv_bs = a->kv_batch_stride; p.o_bs = a->o_batch_stride;
+    p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride;
+    p.causal = a->causal; p.q_pos0 = a->q_pos0;
+    p.scale_log2 = a->scale * 1.4426950408889634f;
+    const dim3 grid(cdiv(a->Tq, QT), a->n_q, a->B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 2 * (size_t)KT * a->hd * sz;
+    if (a->dtype == AFHIP_BF16) {
+        if (a->hd == 64) hipLaunchKernelGGL((attn_kernel<bf16, 64>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, lds, s, p);
+    } else {
+        if (a->hd == 64) hipLaunchKernelGGL((attn_kernel<float, 64>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, lds, s, p);
+    }
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}

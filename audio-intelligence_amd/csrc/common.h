@@ -1,0 +1,86 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the AF3/UALM forward pass.
+// Wave = 64 lanes everywhere; MFMA 32x32 tiles; f32 accumulation for both storage types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/afhip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define AFHIP_WAVE 64
+
+// ---- error plumbing: every entry point returns 0 or a negative code; message kept per thread ----
+void afhip_set_error(const char* fmt, ...);
+#define AFHIP_CHECK(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            afhip_set_error(__VA_ARGS__);                        \
+            return AFHIP_ERR_INVALID;                            \
+        }                                                        \
+    } while (0)
+#define AFHIP_LAUNCH_CHECK()                                                        \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            afhip_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return AFHIP_ERR_LAUNCH;                                                \
+        }                                                                           \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dt) { return dt == AFHIP_BF16 ? 2 : 4; }
+
+// ---- element access in f32 regardless of storage type ----
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---- wave-level reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- MFMA "K=16 step" on 32x32 tiles, uniform over storage types ----
+// Lane l = (r = l & 31, h = l >> 5) holds 8 consecutive K elements [16*step + 8*h, +8) of row r of the
+// A tile (M x K, K contiguous) and of row r of the B^T tile (N x K, K contiguous).
+//   bf16: one v_mfma_f32_32x32x16_bf16 (hardware lane map is exactly this one).
+//   f32 : eight v_mfma_f32_32x32x2_f32; instruction j consumes element j of both lanes' fragments, so the
+//         k index (h, j) is paired consistently on both operands and the 16 products are all summed.
+template <typename T> struct Frag8;
+template <> struct Frag8<bf16> { typedef bf16x8 type; };
+template <> struct Frag8<float> { typedef f32x8 type; };
+
+__device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(f32x8 a, f32x8 b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+// C/D map of every 32x32 MFMA on gfx950: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// 16-byte vector load/store helpers
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -1,0 +1,167 @@
+"""Tensor-level wrappers over the C ABI (device pointers + current HIP stream). PyTorch is plumbing here:
+it owns device memory and streams; all arithmetic happens in csrc/."""
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise L.AfhipError(f"{name}: expected a CUDA/HIP tensor (no CPU fallback)")
+    return t
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
+         residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, out: Optional[torch.Tensor] = None,
+         conv: Optional[tuple] = None) -> torch.Tensor:
+    """C = epilogue(A @ W^T). a [M,K] (or x [B,Tin,C] with conv=(Tout, stride)), w [N,K]."""
+    lib = L.lib()
+    _chk(a, "gemm.a"), _chk(w, "gemm.w")
+    dt = L.dtype_code(a.dtype)
+    N, K = w.shape
+    args = L.GemmArgs()
+    if conv is not None:
+        Bc, Tin, Cc = a.shape
+        Tout, stride = conv
+        M = Bc * Tout
+        assert a.is_contiguous() and K == 3 * Cc
+        args.conv_Tin, args.conv_Tout, args.conv_stride, args.conv_C = Tin, Tout, stride, Cc
+        args.lda = Cc
+    else:
+        assert a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K
+        M = a.shape[0]
+        args.lda = a.stride(0)
+    assert w.stride(1) == 1 and w.dtype == a.dtype
+    n_out = N // 2 if act == L.ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape[0] == M and out.shape[1] == n_out
+    args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.residual = residual.data_ptr() if residual is not None else None
+    args.M, args.N, args.K = M, N, K
+    args.ldw, args.ldc = w.stride(0), out.stride(0)
+    args.ldres = residual.stride(0) if residual is not None else 0
+    args.dtype, args.act, args.res_row_mod = dt, act, res_row_mod
+    L.check(lib.afhip_gemm(C.byref(args), L.stream_ptr()))
+    return out
+
+
+def layernorm(x, w, b, eps: float = 1e-5):
+    lib = L.lib()
+    _chk(x, "layernorm.x")
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous()
+    y = torch.empty_like(x2)
+    L.check(lib.afhip_layernorm(L.ptr(x2), L.ptr(w), L.ptr(b), L.ptr(y), x2.shape[0], x2.shape[1], eps, L.dtype_code(x.dtype), L.stream_ptr()))
+    return y.view(x.shape)
+
+
+def avgpool_ln(x, w, b, eps: float = 1e-5):
+    """x [B, 2*Tout, D] -> LayerNorm(mean of adjacent row pairs) [B, Tout, D]."""
+    lib = L.lib()
+    _chk(x, "avgpool_ln.x")
+    B, T2, D = x.shape
+    assert x.is_contiguous() and T2 % 2 == 0
+    y = torch.empty((B, T2 // 2, D), dtype=x.dtype, device=x.device)
+    L.check(lib.afhip_avgpool_ln(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, T2 // 2, D, eps, L.dtype_code(x.dtype), L.stream_ptr()))
+    return y
+
+
+def rmsnorm(x, w, eps: float = 1e-6):
+    lib = L.lib()
+    _chk(x, "rmsnorm.x")
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous()
+    y = torch.empty_like(x2)
+    L.check(lib.afhip_rmsnorm(L.ptr(x2), L.ptr(w), L.ptr(y), x2.shape[0], x2.shape[1], eps, L.dtype_code(x.dtype), L.stream_ptr()))
+    return y.view(x.shape)
+
+
+def embed_sum(ids: torch.Tensor, table: torch.Tensor):
+    """ids [..., S] int64 -> sum over streams of table rows [..., H]."""
+    lib = L.lib()
+    _chk(ids, "embed_sum.ids")
+    S = ids.shape[-1]
+    ids2 = ids.reshape(-1, S).contiguous()
+    out = torch.empty((ids2.shape[0], table.shape[1]), dtype=table.dtype, device=table.device)
+    L.check(lib.afhip_embed_sum(L.ptr(ids2), L.ptr(table), L.ptr(out), ids2.shape[0], S, table.shape[1], table.shape[0],
+                                L.dtype_code(table.dtype), L.stream_ptr()))
+    return out.view(*ids.shape[:-1], table.shape[1])
+
+
+def transpose_cast(x: torch.Tensor, out_dtype=None):
+    """[B,R,C] -> [B,C,R] (+ dtype change)."""
+    lib = L.lib()
+    _chk(x, "transpose_cast.x")
+    B, R, Cc = x.shape
+    assert x.is_contiguous()
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((B, Cc, R), dtype=out_dtype, device=x.device)
+    L.check(lib.afhip_transpose_cast(L.ptr(x), L.ptr(y), B, R, Cc, L.dtype_code(x.dtype), L.dtype_code(out_dtype), L.stream_ptr()))
+    return y
+
+
+def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Tensor] = None, causal: bool = False):
+    """Self-attention on fused rows qkv [B,T,3*d] (q|k|v, heads contiguous inside each) -> [B,T,d]."""
+    lib = L.lib()
+    _chk(qkv, "attention.qkv")
+    B, T, D3 = qkv.shape
+    d = D3 // 3
+    hd = d // n_heads
+    assert qkv.is_contiguous()
+    out = torch.empty((B, T, d), dtype=qkv.dtype, device=qkv.device)
+    sz = qkv.element_size()
+    a = L.AttnArgs()
+    a.q, a.k, a.v = qkv.data_ptr(), qkv.data_ptr() + d * sz, qkv.data_ptr() + 2 * d * sz
+    a.out = out.data_ptr()
+    a.key_len = key_len.data_ptr() if key_len is not None else None
+    a.B, a.Tq, a.Tk, a.n_q, a.n_kv, a.hd = B, T, T, n_heads, n_heads, hd
+    a.ld_q = a.ld_kv = D3
+    a.ld_o = d
+    a.q_batch_stride = a.kv_batch_stride = T * D3
+    a.o_batch_stride = T * d
+    a.q_head_stride = a.kv_head_stride = hd
+    a.causal, a.q_pos0, a.scale, a.dtype = int(causal), 0, 1.0 / math.sqrt(hd), L.dtype_code(qkv.dtype)
+    L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
+    return out
+
+
+def attention_cache(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int, tk: int,
+                    q_pos0: int, ld_q: Optional[int] = None):
+    """Causal GQA attention of q rows [B,Tq,(>=)n_q*hd] against a KV cache [B,n_kv,cap,hd] holding tk valid keys."""
+    lib = L.lib()
+    _chk(q, "attention.q")
+    B, Tq = q.shape[0], q.shape[1]
+    cap, hd = k_cache.shape[2], k_cache.shape[3]
+    out = torch.empty((B, Tq, n_q * hd), dtype=q.dtype, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr()
+    a.key_len = None
+    a.B, a.Tq, a.Tk, a.n_q, a.n_kv, a.hd = B, Tq, tk, n_q, n_kv, hd
+    a.ld_q = ld_q if ld_q is not None else q.stride(1)
+    a.ld_kv, a.ld_o = hd, n_q * hd
+    a.q_batch_stride = q.stride(0)
+    a.kv_batch_stride = n_kv * cap * hd
+    a.o_batch_stride = Tq * n_q * hd
+    a.q_head_stride, a.kv_head_stride = hd, cap * hd
+    a.causal, a.q_pos0, a.scale, a.dtype = 1, q_pos0, 1.0 / math.sqrt(hd), L.dtype_code(q.dtype)
+    L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
+    return out
+
+
+def rope_kv(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, k_cache: torch.Tensor, v_cache: torch.Tensor,
+            n_q: int, n_kv: int):
+    """In-place RoPE on q of qkv [B,T,(n_q+2n_kv)*hd]; rotated k and v appended to caches [B,n_kv,cap,hd] at pos0.."""
+    lib = L.lib()
+    _chk(qkv, "rope_kv.qkv")
+    B, T, ld = qkv.shape
+    cap, hd = k_cache.shape[2], k_cache.shape[3]
+    assert qkv.is_contiguous() and cos.dtype == torch.float32 and cos.shape[1] == hd // 2
+    L.check(lib.afhip_rope_kv(L.ptr(qkv), ld, L.ptr(cos), L.ptr(sin), pos0, L.ptr(k_cache), L.ptr(v_cache), B, T, n_q, n_kv, hd,
+                              cap, cos.shape[0], L.dtype_code(qkv.dtype), L.stream_ptr()))
+    return qkv

@@ -1,0 +1,214 @@
+/*
+ * afhip.h -- C ABI of the MI355X (gfx950) library behind the AF3 / UALM audio-understanding forward pass.
+ *
+ * The reference (NVIDIA/audio-intelligence, UALM/) is pure Python and has no FFI; its boundary for this
+ * path is the Python plugin interface (AbsIO / ContinuousAudioIO / AFWhisperEncoder / ParallelLLM).  This
+ * header is the native boundary a maintainer binds *under* those classes (ctypes stub: INTEGRATION.md).
+ * Each entry point names the reference code whose arithmetic it replaces (paths relative to
+ * UALM/models/ualm/ unless absolute).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
+ *     nothing synchronises, allocates or frees: entry points are graph-capturable;
+ *   - dtype: AFHIP_F32 (parity mode, exact-f32 MFMA) or AFHIP_BF16 (throughput mode, f32 accumulate);
+ *   - return 0 on success, negative AFHIP_ERR_* otherwise; afhip_last_error() gives the message.
+ *     Nothing aborts the process (the reference's callers catch Exception and continue,
+ *     scripts/inference.py:271-279).
+ */
+#ifndef AFHIP_H
+#define AFHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFHIP_F32 0
+#define AFHIP_BF16 1
+
+#define AFHIP_ERR_INVALID (-1)
+#define AFHIP_ERR_LAUNCH (-2)
+#define AFHIP_ERR_WORKSPACE (-3)
+
+#define AFHIP_ACT_NONE 0
+#define AFHIP_ACT_GELU 1   /* erf GELU (modeling_whisper.py:690-691,502) */
+#define AFHIP_ACT_SWIGLU 2 /* silu(gate)*up on 32-row interleaved gate/up weights (modeling_qwen2.py:46-48) */
+
+int afhip_version(void);
+const char* afhip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * log-mel front end.  Replaces transformers WhisperFeatureExtractor._torch_extract_fbank_features
+ * (/usr/local/lib/python3.10/dist-packages/transformers/models/whisper/feature_extraction_whisper.py:135-170)
+ * as called from multimodal_io/audio.py:1056-1069 (ContinuousAudioIO.preprocess).
+ *   wav      [B, n_samples] f32, n_samples <= 480000 (shorter clips are zero-padded on the fly, :1056-1057)
+ *   mel_out  layout 0: [B,128,3000] (extractor layout)   layout 1: [B,3000,128] (preprocess / encode_batch layout)
+ *            out_dtype AFHIP_F32 or AFHIP_BF16 (the cast scripts/inference.py:272 applies)
+ *   filters  [201,128] f32 mel filter bank (transformers/audio_utils.py:638-729), window [400] f32 periodic Hann
+ *   workspace >= afhip_log_mel_workspace_bytes(B)
+ */
+size_t afhip_log_mel_workspace_bytes(int B);
+int afhip_log_mel(const float* wav, int B, int n_samples, int wav_stride, void* mel_out, int layout, int out_dtype,
+                  const float* filters, const float* window, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T): the arithmetic of every nn.Linear / nn.Conv1d on the path
+ * (modeling_whisper.py:132-135,467-468,614-615; lm/parallel.py:146-149; modeling_qwen2.py:35-49,195-235).
+ *   epilogue: + bias[N]  -> act -> + residual[m % res_row_mod or m, N]
+ *   conv_C > 0: A is X[B,conv_Tin,conv_C] and row m=(b,t) of the implicit im2col matrix is
+ *               [X[b, t*stride-1], X[b, t*stride], X[b, t*stride+1]] (kernel 3, pad 1); W is [N, 3*conv_C].
+ *   K % 64 == 0 (bf16) / K % 32 == 0 (f32).  ACT_SWIGLU: N counts gate+up rows, C is [M, N/2].
+ */
+typedef struct {
+    const void* A;
+    const void* W;
+    const void* bias;     /* may be NULL */
+    const void* residual; /* may be NULL */
+    void* C;
+    int M, N, K;
+    int lda, ldw, ldc, ldres;
+    int dtype;
+    int act;
+    int res_row_mod;
+    int conv_Tin, conv_Tout, conv_stride, conv_C;
+} afhip_gemm_args;
+int afhip_gemm(const afhip_gemm_args* args, void* stream);
+
+/* Skinny GEMM for decode (M <= 64): weight-streaming, HBM-bound.  Same math as afhip_gemm, act NONE only. */
+int afhip_gemm_skinny(const afhip_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-wise normalisation and element-wise pieces.
+ *   layernorm   : nn.LayerNorm eps 1e-5 (modeling_whisper.py:490,501,748)
+ *   avgpool_ln  : AvgPool1d(2,2) over time then LayerNorm (modeling_whisper.py:744-748); x [B,2*Tout,D] -> y [B,Tout,D]
+ *   rmsnorm     : Qwen2RMSNorm (modeling_qwen2.py:238-252)
+ *   embed_sum   : embed_tokens(ids).sum(dim=2) (lm/parallel.py:260,580); ids [n_tok, S] int64
+ *   rope_kv     : rotate-half RoPE on q,k of a fused qkv buffer [B*T, ld_qkv] (token (b,t) sits at position pos0+t)
+ *                 and append of k,v to the cache [B,n_kv,cap,hd] (modeling_qwen2.py:105-136,219-222; replaces
+ *                 DynamicCache.update's torch.cat); cos/sin tables [rope_max_pos, hd/2] f32
+ *   transpose_cast: [B,R,C] -> [B,C,R] with dtype change (mel layout [B,128,3000] <-> [B,3000,128])
+ */
+int afhip_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, int dtype, void* stream);
+int afhip_avgpool_ln(const void* x, const void* w, const void* b, void* y, int B, int Tout, int D, float eps, int dtype, void* stream);
+int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float eps, int dtype, void* stream);
+int afhip_embed_sum(const int64_t* ids, const void* table, void* out, int n_tok, int S, int H, int vocab, int dtype, void* stream);
+int afhip_rope_kv(void* qkv, int ld_qkv, const float* cos_table, const float* sin_table, int pos0,
+                  void* k_cache, void* v_cache, int B, int T, int n_q, int n_kv, int hd, int cache_cap,
+                  int rope_max_pos, int dtype, void* stream);
+int afhip_transpose_cast(const void* x, void* y, int B, int R, int C, int in_dtype, int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention (flash-style, never materialises [T,T] scores).
+ *   softmax(q k^T * scale + mask) v, replaces modeling_whisper.py:186-203 / 418-425 (encoder; additive
+ *   key-padding mask of audio.py:1147-1161 given as key_len[B]) and modeling_qwen2.py:150-173 (LLM, causal, GQA).
+ *   q[b,t,h,:] = q + b*q_batch_stride + t*ld_q + h*q_head_stride (elements); k/v likewise with the kv strides
+ *   (packed qkv rows and the [B,n_kv,cap,hd] cache are both expressible); out [B,Tq,n_q*hd], row stride ld_o.
+ *   key_len[b] (may be NULL): keys >= key_len[b] are masked.  causal: key j visible to query i iff j <= i + q_pos0.
+ */
+typedef struct {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    const int32_t* key_len;
+    int B, Tq, Tk, n_q, n_kv, hd;
+    int ld_q, ld_kv, ld_o;
+    long long q_batch_stride, kv_batch_stride, o_batch_stride;
+    long long q_head_stride, kv_head_stride; /* elements between heads (hd for packed rows, cap*hd for the KV cache) */
+    int causal, q_pos0;
+    float scale;
+    int dtype;
+} afhip_attn_args;
+int afhip_attention(const afhip_attn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AF-Whisper encoder forward.  Replaces AFWhisperEncoder.forward (modeling_whisper.py:640-756), the mask
+ * construction of ContinuousAudioIO.encode_batch (audio.py:1129-1161) and SoundTower.forward
+ * (sound_encoder.py:81-107): the key-padding mask is the per-clip feat_len vector, never a [B,1,1500,1500] tensor.
+ * Weights are packed once by the host side (python: AFWhisperEncoder.pack()): conv weights as [d, 3*C]
+ * (tap-major), q/k/v fused as [3d, d] with a zero k-bias section.
+ */
+typedef struct {
+    int n_mels, d_model, n_heads, ffn_dim, n_layers, max_pos; /* 128,1280,20,5120,32,1500 */
+    int dtype;
+    const void* conv1_w; const void* conv1_b; /* [d, 3*n_mels], [d] */
+    const void* conv2_w; const void* conv2_b; /* [d, 3*d], [d] */
+    const void* pos_emb;                      /* [max_pos, d] */
+    const void* const* ln1_w; const void* const* ln1_b; /* per layer */
+    const void* const* qkv_w; const void* const* qkv_b; /* [3d, d], [3d] */
+    const void* const* out_w; const void* const* out_b;
+    const void* const* ln2_w; const void* const* ln2_b;
+    const void* const* fc1_w; const void* const* fc1_b;
+    const void* const* fc2_w; const void* const* fc2_b;
+    const void* lnf_w; const void* lnf_b;
+} afhip_encoder_weights;
+size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
+/* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);
+ * out [B, max_pos/2, d]; hidden_out (optional, may be NULL): [B, max_pos, d] pre-pool states of layer `hidden_layer`
+ * (-1 = conv stem) for parity tests. */
+int afhip_encoder_forward(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, int B,
+                          void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LLM (Qwen2 decoder stack + UALM head).  Replaces ParallelLLM._step (lm/parallel.py:570-597) over
+ * transformers Qwen2Model (modeling_qwen2.py:258-299) with a preallocated KV cache instead of DynamicCache.
+ */
+typedef struct {
+    int hidden, n_layers, n_q, n_kv, hd, inter, vocab, n_stream;
+    float rms_eps;
+    int dtype;
+    const void* embed;                          /* [vocab, hidden] */
+    const void* const* ln1_w;                   /* input_layernorm */
+    const void* const* qkv_w; const void* const* qkv_b; /* [(n_q+2 n_kv) hd, hidden] */
+    const void* const* o_w;                     /* [hidden, n_q hd] */
+    const void* const* ln2_w;                   /* post_attention_layernorm */
+    const void* const* gu_w;                    /* [2 inter, hidden], gate/up interleaved in 32-row blocks */
+    const void* const* down_w;                  /* [hidden, inter] */
+    const void* norm_w;
+    const void* lm_head;                        /* [vocab, hidden] */
+    const void* stream_emb;                     /* [n_stream, hidden] */
+    const float* rope_cos; const float* rope_sin; /* [max_pos, hd/2] f32 (modeling_qwen2.py:91-103) */
+    int rope_max_pos;
+} afhip_llm_weights;
+
+typedef struct {
+    void* k; void* v;      /* [n_layers, B, n_kv, cap, hd] */
+    int cap, B;
+} afhip_kv_cache;
+
+size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T);
+/* Forward T tokens per sequence from embeddings x [B,T,hidden] starting at cache position pos0; appends K/V.
+ * hidden_out [B,T,hidden] = final-normed hidden states (model.norm applied). */
+int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
+                      void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* logits[r, s, :] = (hidden[r] + (s ? stream_emb[s] : 0)) . lm_head^T for s < n_s (lm/parallel.py:588-592); f32 out. */
+int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int rows, int n_s, float* logits, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* Masked greedy pick on stream 0 (lm/parallel.py:594-601): argmax over ids inside `allowed` half-open intervals
+ * [lo,hi) (n_iv of them, int32 pairs) with first-index tie-break; writes int64 token[r]. */
+int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
+                        void* stream);
+
+/* One greedy decode step for B sequences entirely on device: embed prev token (stream 0 = token, others pad),
+ * forward 1 position, lm_head on stream 0, masked argmax, append to out_tokens[step], update finished flags
+ * (eos/eot, lm/parallel.py:503-513).  No host sync. */
+typedef struct {
+    int64_t* prev_token;     /* [B] in/out */
+    int64_t* out_tokens;     /* [max_step, B] */
+    int32_t* finished_at;    /* [B], -1 while running */
+    const int32_t* allowed;  /* [n_iv,2] */
+    int n_iv;
+    int eos_id, eot_id;
+} afhip_decode_state;
+int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache* cache, afhip_decode_state* st, int B, int pos,
+                          int step, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFHIP_H */
