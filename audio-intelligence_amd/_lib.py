@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldres", C.c_int),
                 ("dtype", C.c_int), ("act", C.c_int), ("res_row_mod", C.c_int),
-                ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int)]
+                ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int),
+                ("out_f32", C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -71,8 +72,10 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "afhip_version": (_I, []),
     "afhip_last_error": (C.c_char_p, []),
+    "afhip_log_mel_tables_bytes": (_Z, []),
+    "afhip_log_mel_tables_host": (_I, [_P, _P]),
     "afhip_log_mel_workspace_bytes": (_Z, [_I]),
-    "afhip_log_mel": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "afhip_log_mel": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "afhip_gemm": (_I, [C.POINTER(GemmArgs), _P]),
     "afhip_gemm_skinny": (_I, [C.POINTER(GemmArgs), _P]),
     "afhip_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),

@@ -1,0 +1,111 @@
+// AF-Whisper encoder forward: host-side sequencing of the HIP kernels on one stream (no sync, no allocation).
+// Mirrors AFWhisperEncoder.forward (modeling_whisper.py:640-756) + Qwen2AudioEncoderLayer.forward (:471-519);
+// the additive [B,1,1500,1500] mask of audio.py:1147-1161 / sound_encoder.py:88-103 is the feat_len vector.
+//   stem : conv1 (implicit GEMM, +bias, GELU) -> conv2 (stride 2, +bias, GELU, + position table)
+//   layer: LN -> fused QKV GEMM (k bias = 0) -> flash attention -> out-proj GEMM (+bias, +residual in place)
+//          LN -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias, +residual in place)
+//   tail : AvgPool1d(2,2) + LayerNorm fused
+#include "common.h"
+
+namespace {
+
+struct EncWs {
+    char* h;     // [B*Tp, d]
+    char* big;   // max(B*2Tp*d, B*Tp*ffn)
+    char* ln;    // [B*Tp, d]
+    char* qkv;   // [B*Tp, 3d]
+    char* att;   // [B*Tp, d]
+    size_t total;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+EncWs carve(const afhip_encoder_weights* w, int B, char* base) {
+    const size_t sz = dtype_size(w->dtype);
+    const size_t Tp = w->max_pos, d = w->d_model, f = w->ffn_dim;
+    const size_t rows = (size_t)B * Tp;
+    EncWs ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    ws.h = take(rows * d * sz);
+    const size_t big_elems = (2 * rows * d > rows * f) ? 2 * rows * d : rows * f;
+    ws.big = take(big_elems * sz);
+    ws.ln = take(rows * d * sz);
+    ws.qkv = take(rows * 3 * d * sz);
+    ws.att = take(rows * d * sz);
+    ws.total = off;
+    return ws;
+}
+
+int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+         int ldres, int dtype, int act, int row_mod, hipStream_t s, int cTin = 0, int cTout = 0, int cStride = 0, int cC = 0) {
+    afhip_gemm_args g;
+    g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
+    g.dtype = dtype; g.act = act; g.res_row_mod = row_mod;
+    g.conv_Tin = cTin; g.conv_Tout = cTout; g.conv_stride = cStride; g.conv_C = cC;
+    g.out_f32 = 0;
+    return afhip_gemm(&g, s);
+}
+
+}  // namespace
+
+extern "C" size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B) {
+    if (!w || B <= 0) return 0;
+    return carve(w, B, nullptr).total;
+}
+
+extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, int B,
+                                     void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    AFHIP_CHECK(w && mel_btc && out && workspace, "afhip_encoder_forward: null pointer");
+    AFHIP_CHECK(B > 0, "afhip_encoder_forward: bad batch %d", B);
+    AFHIP_CHECK(w->dtype == AFHIP_F32 || w->dtype == AFHIP_BF16, "afhip_encoder_forward: bad dtype %d", w->dtype);
+    AFHIP_CHECK(w->d_model > 0 && w->n_heads > 0 && w->d_model % w->n_heads == 0, "afhip_encoder_forward: bad d_model/heads %d/%d", w->d_model, w->n_heads);
+    const int hd = w->d_model / w->n_heads;
+    AFHIP_CHECK(hd == 64 || hd == 128, "afhip_encoder_forward: head_dim %d unsupported", hd);
+    AFHIP_CHECK(w->max_pos > 0 && w->max_pos % 2 == 0 && w->n_layers >= 0 && w->n_mels > 0, "afhip_encoder_forward: bad config");
+    AFHIP_CHECK(hidden_layer >= -1 && hidden_layer < w->n_layers, "afhip_encoder_forward: hidden_layer %d out of range", hidden_layer);
+    const EncWs ws = carve(w, B, (char*)workspace);
+    if (workspace_bytes < ws.total) {
+        afhip_set_error("afhip_encoder_forward: workspace %zu < required %zu bytes", workspace_bytes, ws.total);
+        return AFHIP_ERR_WORKSPACE;
+    }
+    AFHIP_CHECK(((uintptr_t)workspace % 256) == 0, "afhip_encoder_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = w->dtype;
+    const size_t sz = dtype_size(dt);
+    const int d = w->d_model, f = w->ffn_dim, Tp = w->max_pos, Tm = 2 * w->max_pos, nm = w->n_mels;
+    const int rows = B * Tp;
+    int rc;
+
+    // conv stem (modeling_whisper.py:690-696)
+    if ((rc = gemm(mel_btc, w->conv1_w, w->conv1_b, nullptr, ws.big, B * Tm, d, 3 * nm, nm, d, 0, dt, AFHIP_ACT_GELU, 0, s, Tm, Tm, 1, nm))) return rc;
+    if ((rc = gemm(ws.big, w->conv2_w, w->conv2_b, w->pos_emb, ws.h, rows, d, 3 * d, d, d, d, dt, AFHIP_ACT_GELU, Tp, s, Tm, Tp, 2, d))) return rc;
+    if (hidden_out && hidden_layer == -1) {
+        if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
+    }
+
+    for (int l = 0; l < w->n_layers; ++l) {
+        if ((rc = afhip_layernorm(ws.h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+        if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        afhip_attn_args a;
+        a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = ws.att;
+        a.key_len = feat_len;
+        a.B = B; a.Tq = Tp; a.Tk = Tp; a.n_q = w->n_heads; a.n_kv = w->n_heads; a.hd = hd;
+        a.ld_q = 3 * d; a.ld_kv = 3 * d; a.ld_o = d;
+        a.q_batch_stride = (long long)Tp * 3 * d; a.kv_batch_stride = (long long)Tp * 3 * d; a.o_batch_stride = (long long)Tp * d;
+        a.q_head_stride = hd; a.kv_head_stride = hd;
+        a.causal = 0; a.q_pos0 = 0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        if ((rc = afhip_attention(&a, s))) return rc;
+        if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if ((rc = afhip_layernorm(ws.h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+        if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
+        if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if (hidden_out && hidden_layer == l) {
+            if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
+        }
+    }
+    return afhip_avgpool_ln(ws.h, w->lnf_w, w->lnf_b, out, B, Tp / 2, d, 1e-5f, dt, s);
+}

@@ -23,6 +23,7 @@ struct GemmP {
     int act, res_row_mod;
     int conv_Tin, conv_Tout, conv_stride, conv_C;
     int tiles_m, tiles_n;
+    int out_f32;
 };
 
 // bijective XCD-aware remap of a linear workgroup id (blocks b and b+8 share an XCD under round-robin dispatch):
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                         const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
                         v += to_f32<T>(res[(long long)rm * p.ldres + n]);
                     }
-                    C[(long long)m * p.ldc + n] = from_f32<T>(v);
+                    if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)m * p.ldc + n] = v;
+                    else C[(long long)m * p.ldc + n] = from_f32<T>(v);
                 }
             }
     }
@@ -225,7 +227,7 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
         AFHIP_CHECK(a->lda >= a->K && a->ldw >= a->K, "afhip_gemm: lda/ldw < K");
     }
     if (a->act == AFHIP_ACT_SWIGLU) {
-        AFHIP_CHECK(a->N % 64 == 0 && !a->bias && !a->residual, "afhip_gemm: SWIGLU needs N%%64==0, no bias/residual");
+        AFHIP_CHECK(a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm: SWIGLU needs N%%64==0, no bias/residual/out_f32");
         AFHIP_CHECK(a->ldc >= a->N / 2, "afhip_gemm: ldc < N/2");
     } else {
         AFHIP_CHECK(a->ldc >= a->N, "afhip_gemm: ldc < N");
@@ -240,6 +242,7 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     p.act = a->act; p.res_row_mod = a->res_row_mod;
     p.conv_Tin = a->conv_Tin; p.conv_Tout = a->conv_Tout; p.conv_stride = a->conv_stride; p.conv_C = a->conv_C;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+    p.out_f32 = a->out_f32;
     const long long nwg = (long long)p.tiles_m * p.tiles_n;
     AFHIP_CHECK(nwg < (1ll << 31), "afhip_gemm: grid too large");
     const size_t lds = 4 * TILE_BYTES;

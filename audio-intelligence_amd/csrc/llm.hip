@@ -1,0 +1,260 @@
+// Qwen2 decoder stack + UALM head on gfx950: host-side sequencing (one stream, no sync, no allocation) and the
+// small head kernels.  Mirrors ParallelLLM._step (lm/parallel.py:570-597) over transformers Qwen2Model
+// (modeling_qwen2.py:258-299), with a preallocated [layer][B][kv_head][cap][hd] KV cache instead of DynamicCache,
+// and the greedy pick + stop bookkeeping of lm/parallel.py:494-513,599-601 kept on the device.
+#include "common.h"
+
+namespace {
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct LlmWs {
+    char* x;     // [rows, H] residual stream
+    char* nb;    // [rows, H]
+    char* qkv;   // [rows, (nq + 2 nkv) hd]
+    char* att;   // [rows, nq hd]
+    char* act;   // [rows, 2*inter] (skinny path) / [rows, inter]
+    char* act2;  // [rows, inter]
+    size_t total;
+};
+
+LlmWs carve(const afhip_llm_weights* w, int rows, char* base) {
+    const size_t sz = dtype_size(w->dtype);
+    const size_t H = w->hidden, qw = (size_t)(w->n_q + 2 * w->n_kv) * w->hd;
+    LlmWs ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    ws.x = take((size_t)rows * H * sz);
+    ws.nb = take((size_t)rows * H * sz);
+    ws.qkv = take((size_t)rows * qw * sz);
+    ws.att = take((size_t)rows * w->n_q * w->hd * sz);
+    ws.act = take((size_t)rows * 2 * w->inter * sz);
+    ws.act2 = take((size_t)rows * w->inter * sz);
+    ws.total = off;
+    return ws;
+}
+
+int gemm_any(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+             int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s) {
+    afhip_gemm_args g;
+    g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
+    g.dtype = dtype; g.act = act; g.res_row_mod = 0;
+    g.conv_Tin = g.conv_Tout = g.conv_stride = g.conv_C = 0;
+    g.out_f32 = out_f32;
+    if (M <= 64 && act == AFHIP_ACT_NONE) return afhip_gemm_skinny(&g, s);
+    return afhip_gemm(&g, s);
+}
+
+// y[r, j] = silu(gu[r, 64*(j/32) + j%32]) * gu[r, 64*(j/32) + 32 + j%32]   (32-row interleaved gate/up)
+template <typename T>
+__global__ void swiglu_interleaved_kernel(const T* __restrict__ gu, T* __restrict__ y, int rows, int inter) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * inter) return;
+    const int r = (int)(i / inter), j = (int)(i % inter);
+    const T* row = gu + (long long)r * 2 * inter + 64 * (j >> 5) + (j & 31);
+    y[i] = from_f32<T>(silu(to_f32<T>(row[0])) * to_f32<T>(row[32]));
+}
+
+// hs[(r*n_s + s), :] = hidden[r, :] + (s ? stream_emb[s, :] : 0)      (lm/parallel.py:588-591)
+template <typename T>
+__global__ void add_stream_emb_kernel(const T* __restrict__ hidden, const T* __restrict__ se, T* __restrict__ hs, int rows,
+                                      int n_s, int H) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * n_s * H) return;
+    const int c = (int)(i % H);
+    const long long rs = i / H;
+    const int s = (int)(rs % n_s);
+    const long long r = rs / n_s;
+    float v = to_f32<T>(hidden[r * H + c]);
+    if (s > 0) v = to_f32<T>(from_f32<T>(v + to_f32<T>(se[(long long)s * H + c])));
+    hs[i] = from_f32<T>(v);
+}
+
+// first-index argmax over the allowed intervals; one workgroup per row
+__global__ __launch_bounds__(1024) void masked_argmax_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ iv,
+                                                             int n_iv, int64_t* __restrict__ token) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (long long)r * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = 0; k < n_iv; ++k) {
+        const int lo = iv[2 * k], hi = iv[2 * k + 1];
+        for (int i = lo + tid; i < hi; i += 1024) {
+            const float v = row[i];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        // an all -inf / NaN row falls back to the first allowed id, like argmax over a masked row picks index 0 of ties
+        if (bi == 0x7fffffff) bi = n_iv > 0 ? iv[0] : 0;
+        token[r] = bi;
+    }
+}
+
+// ids[b, 0] = prev[b]; ids[b, 1..S) = 0 (pad)      (prev_token layout of lm/parallel.py:479,540-541)
+__global__ void build_ids_kernel(const int64_t* __restrict__ prev, int64_t* __restrict__ ids, int B, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * S) ids[i] = (i % S == 0) ? prev[i / S] : 0;
+}
+
+__global__ void decode_update_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ prev, int64_t* __restrict__ out_tokens,
+                                     int32_t* __restrict__ finished_at, int B, int step, int eos, int eot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t t = tok[b];
+    out_tokens[(long long)step * B + b] = t;
+    prev[b] = t;
+    if ((t == eos || t == eot) && finished_at[b] < 0) finished_at[b] = step;
+}
+
+}  // namespace
+
+extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    // forward scratch + head scratch (n_stream rows of hidden per token row, f32 logits for one decode step, ids, token)
+    const size_t rows = (size_t)B * T;
+    size_t tot = carve(w, (int)rows, nullptr).total;
+    tot += align256(rows * w->n_stream * w->hidden * dtype_size(w->dtype));
+    tot += align256((size_t)B * w->vocab * sizeof(float));
+    tot += align256((size_t)B * w->n_stream * sizeof(int64_t)) + align256((size_t)B * sizeof(int64_t));
+    tot += align256((size_t)B * w->hidden * dtype_size(w->dtype)) * 2;
+    return tot;
+}
+
+extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
+                                 void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(w && x && cache && hidden_out && workspace, "afhip_llm_forward: null pointer");
+    AFHIP_CHECK(B > 0 && T > 0 && pos0 >= 0, "afhip_llm_forward: bad B=%d T=%d pos0=%d", B, T, pos0);
+    AFHIP_CHECK(w->dtype == AFHIP_F32 || w->dtype == AFHIP_BF16, "afhip_llm_forward: bad dtype");
+    AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_forward: head_dim %d unsupported", w->hd);
+    AFHIP_CHECK(w->n_q % w->n_kv == 0 && w->inter % 32 == 0, "afhip_llm_forward: bad head / intermediate sizes");
+    AFHIP_CHECK(cache->k && cache->v && cache->B >= B, "afhip_llm_forward: cache batch %d < %d", cache->B, B);
+    AFHIP_CHECK(pos0 + T <= cache->cap, "afhip_llm_forward: positions [%d,%d) exceed KV capacity %d", pos0, pos0 + T, cache->cap);
+    AFHIP_CHECK(pos0 + T <= w->rope_max_pos, "afhip_llm_forward: positions exceed rope table %d", w->rope_max_pos);
+    const int rows = B * T;
+    const LlmWs ws = carve(w, rows, (char*)workspace);
+    if (workspace_bytes < ws.total) {
+        afhip_set_error("afhip_llm_forward: workspace %zu < required %zu bytes", workspace_bytes, ws.total);
+        return AFHIP_ERR_WORKSPACE;
+    }
+    AFHIP_CHECK(((uintptr_t)workspace % 256) == 0, "afhip_llm_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = w->dtype;
+    const size_t sz = dtype_size(dt);
+    const int H = w->hidden, nq = w->n_q, nkv = w->n_kv, hd = w->hd, I = w->inter;
+    const int qw = (nq + 2 * nkv) * hd;
+    const size_t layer_kv = (size_t)cache->B * nkv * cache->cap * hd * sz;
+    int rc;
+    if (hipMemcpyAsync(ws.x, x, (size_t)rows * H * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("llm: input copy failed"); return AFHIP_ERR_LAUNCH; }
+
+    for (int l = 0; l < w->n_layers; ++l) {
+        char* kc = (char*)cache->k + (size_t)l * layer_kv;
+        char* vc = (char*)cache->v + (size_t)l * layer_kv;
+        if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
+        if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if ((rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
+        afhip_attn_args a;
+        a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
+        a.B = B; a.Tq = T; a.Tk = pos0 + T; a.n_q = nq; a.n_kv = nkv; a.hd = hd;
+        a.ld_q = qw; a.ld_kv = hd; a.ld_o = nq * hd;
+        a.q_batch_stride = (long long)T * qw; a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.o_batch_stride = (long long)T * nq * hd;
+        a.q_head_stride = hd; a.kv_head_stride = (long long)cache->cap * hd;
+        a.causal = 1; a.q_pos0 = pos0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        if ((rc = afhip_attention(&a, s))) return rc;
+        if ((rc = gemm_any(ws.att, w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if ((rc = afhip_rmsnorm(ws.x, w->ln2_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
+        const char* mlp_in;
+        if (rows <= 64) {
+            if ((rc = gemm_any(ws.nb, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, 2 * I, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            const long long n = (long long)rows * I;
+            if (dt == AFHIP_BF16) hipLaunchKernelGGL(swiglu_interleaved_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)ws.act, (bf16*)ws.act2, rows, I);
+            else hipLaunchKernelGGL(swiglu_interleaved_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws.act, (float*)ws.act2, rows, I);
+            AFHIP_LAUNCH_CHECK();
+            mlp_in = ws.act2;
+        } else {
+            if ((rc = gemm_any(ws.nb, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s))) return rc;
+            mlp_in = ws.act;
+        }
+        if ((rc = gemm_any(mlp_in, w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+    }
+    return afhip_rmsnorm(ws.x, w->norm_w, hidden_out, rows, H, w->rms_eps, dt, s);
+}
+
+extern "C" int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int rows, int n_s, float* logits, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(w && hidden && logits && workspace, "afhip_lm_head: null pointer");
+    AFHIP_CHECK(rows > 0 && n_s >= 1 && n_s <= w->n_stream, "afhip_lm_head: bad rows=%d n_s=%d", rows, n_s);
+    const int dt = w->dtype, H = w->hidden;
+    const size_t need = align256((size_t)rows * n_s * H * dtype_size(dt));
+    if (workspace_bytes < need) {
+        afhip_set_error("afhip_lm_head: workspace %zu < required %zu bytes", workspace_bytes, need);
+        return AFHIP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const void* a = hidden;
+    if (n_s > 1) {
+        AFHIP_CHECK(w->stream_emb != nullptr, "afhip_lm_head: stream_emb missing");
+        const long long n = (long long)rows * n_s * H;
+        if (dt == AFHIP_BF16) hipLaunchKernelGGL(add_stream_emb_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)hidden, (const bf16*)w->stream_emb, (bf16*)workspace, rows, n_s, H);
+        else hipLaunchKernelGGL(add_stream_emb_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)hidden, (const float*)w->stream_emb, (float*)workspace, rows, n_s, H);
+        AFHIP_LAUNCH_CHECK();
+        a = workspace;
+    }
+    return gemm_any(a, w->lm_head, nullptr, nullptr, logits, rows * n_s, w->vocab, H, H, w->vocab, 0, dt, AFHIP_ACT_NONE, 1, s);
+}
+
+extern "C" int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
+                                   void* stream) {
+    AFHIP_CHECK(logits && allowed && token && rows > 0 && n_iv > 0 && ld > 0, "afhip_masked_argmax: bad args");
+    hipLaunchKernelGGL(masked_argmax_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ld, allowed, n_iv, token);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache* cache, afhip_decode_state* st, int B, int pos,
+                                     int step, void* workspace, size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(w && cache && st && workspace, "afhip_llm_decode_step: null pointer");
+    AFHIP_CHECK(st->prev_token && st->out_tokens && st->finished_at && st->allowed && st->n_iv > 0, "afhip_llm_decode_step: bad state");
+    AFHIP_CHECK(B > 0 && step >= 0, "afhip_llm_decode_step: bad B/step");
+    const size_t need = afhip_llm_workspace_bytes(w, B, 1);
+    if (workspace_bytes < need) {
+        afhip_set_error("afhip_llm_decode_step: workspace %zu < required %zu bytes", workspace_bytes, need);
+        return AFHIP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = w->dtype, H = w->hidden, S = w->n_stream;
+    const size_t sz = dtype_size(dt);
+    char* base = (char*)workspace;
+    size_t off = carve(w, B, nullptr).total;
+    char* hs = base + off; off += align256((size_t)B * S * H * sz);
+    float* logits = (float*)(base + off); off += align256((size_t)B * w->vocab * sizeof(float));
+    int64_t* ids = (int64_t*)(base + off); off += align256((size_t)B * S * sizeof(int64_t));
+    int64_t* tok = (int64_t*)(base + off); off += align256((size_t)B * sizeof(int64_t));
+    char* emb = base + off; off += align256((size_t)B * H * sz);
+    char* hid = base + off; off += align256((size_t)B * H * sz);
+    int rc;
+    hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);
+    AFHIP_LAUNCH_CHECK();
+    if ((rc = afhip_embed_sum(ids, w->embed, emb, B, S, H, w->vocab, dt, s))) return rc;
+    if ((rc = afhip_llm_forward(w, emb, B, 1, pos, cache, hid, workspace, carve(w, B, nullptr).total, s))) return rc;
+    if ((rc = afhip_lm_head(w, hid, B, 1, logits, hs, align256((size_t)B * S * H * sz), s))) return rc;
+    if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, s))) return rc;
+    hipLaunchKernelGGL(decode_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, (const int64_t*)tok, st->prev_token, st->out_tokens,
+                       st->finished_at, B, step, st->eos_id, st->eot_id);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,259 @@
+"""AF-Whisper encoder module backed by the HIP library.
+
+Host-side mirror of `AFWhisperEncoder` (UALM/models/ualm/multimodal_io/modeling_whisper.py:589-765): same
+constructor shape (a config object), same parameter names (so reference checkpoints load with strict=True,
+modeling_whisper.py:132-135,463-469,614-621), same forward signature and the same length helper.  No arithmetic
+happens in torch: forward() hands device pointers to `afhip_encoder_forward`.
+"""
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, asdict
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+
+
+@dataclass
+class AFWhisperEncoderConfig:
+    """Fields of Qwen2AudioEncoderConfig that the encoder reads (defaults = Whisper-large-v3 encoder)."""
+    num_mel_bins: int = 128
+    d_model: int = 1280
+    encoder_attention_heads: int = 20
+    encoder_ffn_dim: int = 5120
+    encoder_layers: int = 32
+    max_source_positions: int = 1500
+    activation_function: str = "gelu"
+    scale_embedding: bool = False
+    pad_token_id: int = 0
+
+    @classmethod
+    def from_dict(cls, d: dict):
+        keys = {f for f in cls.__dataclass_fields__}
+        return cls(**{k: v for k, v in d.items() if k in keys})
+
+
+class _Linear(nn.Module):
+    """Parameter holder with nn.Linear's state-dict layout (weight [out,in], optional bias)."""
+
+    def __init__(self, n_in, n_out, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(n_out), requires_grad=False) if bias else None
+
+
+class _Norm(nn.Module):
+    def __init__(self, d, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(d), requires_grad=False) if bias else None
+
+
+class _Conv1d(nn.Module):
+    def __init__(self, c_in, c_out, k, stride):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c_out, c_in, k), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(c_out), requires_grad=False)
+        self.stride = (stride,)
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = _Linear(d, d, bias=False)   # modeling_whisper.py:132
+        self.v_proj = _Linear(d, d)
+        self.q_proj = _Linear(d, d)
+        self.out_proj = _Linear(d, d)
+
+
+class _Layer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = _Attn(cfg.d_model)
+        self.self_attn_layer_norm = _Norm(cfg.d_model)
+        self.fc1 = _Linear(cfg.d_model, cfg.encoder_ffn_dim)
+        self.fc2 = _Linear(cfg.encoder_ffn_dim, cfg.d_model)
+        self.final_layer_norm = _Norm(cfg.d_model)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, n, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d), requires_grad=False)
+
+
+class AFWhisperEncoder(nn.Module):
+    main_input_name = "input_features"
+
+    def __init__(self, config: AFWhisperEncoderConfig):
+        super().__init__()
+        if config.activation_function != "gelu" or config.scale_embedding:
+            raise ValueError("AF-Whisper uses erf GELU and no embedding scale (modeling_whisper.py:465,612)")
+        self.config = config
+        d = config.d_model
+        self.num_mel_bins = config.num_mel_bins
+        self.max_source_positions = config.max_source_positions
+        self.conv1 = _Conv1d(config.num_mel_bins, d, 3, 1)
+        self.conv2 = _Conv1d(d, d, 3, 2)
+        self.embed_positions = _Embedding(config.max_source_positions, d)
+        self.layers = nn.ModuleList([_Layer(config) for _ in range(config.encoder_layers)])
+        self.layer_norm = _Norm(d)
+        self._packed = None
+        self._ws = None
+
+    # ---------------------------------------------------------------- checkpoints
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, **kwargs):
+        """Reads `config.json` + `model.safetensors` (or `pytorch_model.bin`, weights_only) from a local directory,
+        as `AFWhisperEncoder.from_pretrained(encoder_local_path, torch_dtype=...)` does at audio.py:976-979."""
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = AFWhisperEncoderConfig.from_dict(json.load(f))
+        model = cls(cfg)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd, strict=True)
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        return model
+
+    def save_pretrained(self, path: str):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(asdict(self.config), f, indent=1)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(path, "model.safetensors"))
+
+    def _apply(self, fn, *a, **kw):   # .to() / .cuda() / .half(): packed weights must be rebuilt
+        self._packed = None
+        self._ws = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._packed = None
+        return super().load_state_dict(*a, **kw)
+
+    @property
+    def dtype(self):
+        return self.conv1.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv1.weight.device
+
+    # ---------------------------------------------------------------- packing for the HIP library
+    def pack(self):
+        """Build the layouts `afhip_encoder_forward` wants: conv weights [d, 3*C] tap-major, q|k|v fused [3d, d]
+        with a zero k-bias section.  Done once per device/dtype; keeps the tensors alive in `self._packed`."""
+        if self._packed is not None:
+            return self._packed
+        cfg = self.config
+        dev, dt = self.device, self.dtype
+        if dev.type != "cuda":
+            raise L.AfhipError("AFWhisperEncoder runs on the GPU only: call .to('cuda') first (no CPU fallback)")
+        keep = []
+
+        def P(t):
+            t = t.detach().contiguous()
+            keep.append(t)
+            return t
+
+        w = L.EncoderWeights()
+        w.n_mels, w.d_model, w.n_heads = cfg.num_mel_bins, cfg.d_model, cfg.encoder_attention_heads
+        w.ffn_dim, w.n_layers, w.max_pos, w.dtype = cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.max_source_positions, L.dtype_code(dt)
+        c1 = P(self.conv1.weight.permute(0, 2, 1).reshape(cfg.d_model, -1))
+        c2 = P(self.conv2.weight.permute(0, 2, 1).reshape(cfg.d_model, -1))
+        w.conv1_w, w.conv1_b = c1.data_ptr(), P(self.conv1.bias).data_ptr()
+        w.conv2_w, w.conv2_b = c2.data_ptr(), P(self.conv2.bias).data_ptr()
+        w.pos_emb = P(self.embed_positions.weight).data_ptr()
+        names = ["ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+        lists = {n: [] for n in names}
+        for lyr in self.layers:
+            a = lyr.self_attn
+            lists["ln1_w"].append(P(lyr.self_attn_layer_norm.weight))
+            lists["ln1_b"].append(P(lyr.self_attn_layer_norm.bias))
+            lists["qkv_w"].append(P(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)))
+            lists["qkv_b"].append(P(torch.cat([a.q_proj.bias, torch.zeros_like(a.q_proj.bias), a.v_proj.bias], dim=0)))
+            lists["out_w"].append(P(a.out_proj.weight))
+            lists["out_b"].append(P(a.out_proj.bias))
+            lists["ln2_w"].append(P(lyr.final_layer_norm.weight))
+            lists["ln2_b"].append(P(lyr.final_layer_norm.bias))
+            lists["fc1_w"].append(P(lyr.fc1.weight))
+            lists["fc1_b"].append(P(lyr.fc1.bias))
+            lists["fc2_w"].append(P(lyr.fc2.weight))
+            lists["fc2_b"].append(P(lyr.fc2.bias))
+        arrays = {}
+        for n in names:
+            arrays[n] = L.ptr_array(lists[n])
+            setattr(w, n, C.cast(arrays[n], L.c_void_pp))
+        w.lnf_w, w.lnf_b = P(self.layer_norm.weight).data_ptr(), P(self.layer_norm.bias).data_ptr()
+        self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays)
+        return self._packed
+
+    def _workspace(self, B: int) -> torch.Tensor:
+        lib = L.lib()
+        need = lib.afhip_encoder_workspace_bytes(C.byref(self.pack().w), B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---------------------------------------------------------------- forward
+    def _get_feat_extract_output_lengths(self, input_lengths):
+        """modeling_whisper.py:759-765."""
+        input_lengths = (input_lengths - 1) // 2 + 1
+        output_lengths = (input_lengths - 2) // 2 + 1
+        return input_lengths, output_lengths
+
+    def encode_btc(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, hidden_layer: Optional[int] = None):
+        """mel [B,3000,128] (model dtype, GPU) + optional per-clip key length [B] -> [B,750,d].
+        `hidden_layer` (-1 = conv stem, l = output of layer l) additionally returns that [B,1500,d] state."""
+        lib = L.lib()
+        pk = self.pack()
+        cfg = self.config
+        if mel_btc.dim() != 3 or mel_btc.shape[1] != 2 * cfg.max_source_positions or mel_btc.shape[2] != cfg.num_mel_bins:
+            raise ValueError(f"Qwen2Audio expects the mel input features to be of length {2 * cfg.max_source_positions}, "
+                             f"but found {mel_btc.shape[1]}. Make sure to pad the input mel features to {2 * cfg.max_source_positions}.")
+        mel_btc = mel_btc.to(device=self.device, dtype=self.dtype).contiguous()
+        B = mel_btc.shape[0]
+        fl = None
+        if feat_len is not None:
+            fl = feat_len.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((B, cfg.max_source_positions // 2, cfg.d_model), dtype=self.dtype, device=self.device)
+        hid = None
+        if hidden_layer is not None:
+            hid = torch.empty((B, cfg.max_source_positions, cfg.d_model), dtype=self.dtype, device=self.device)
+        ws = self._workspace(B)
+        L.check(lib.afhip_encoder_forward(C.byref(pk.w), L.ptr(mel_btc), L.ptr(fl), B, L.ptr(out), L.ptr(hid),
+                                          hidden_layer if hidden_layer is not None else -1, L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return (out, hid) if hidden_layer is not None else out
+
+    @torch.no_grad()
+    def forward(self, input_features, attention_mask=None, head_mask=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, feat_len: Optional[torch.Tensor] = None):
+        """Reference signature (modeling_whisper.py:640-648). input_features [B,128,3000]; attention_mask is the
+        additive [B,1,1500,1500] key-padding mask callers build (audio.py:1147-1161): it is reduced to a key length
+        per clip (its rows are identical by construction); pass `feat_len` instead to skip materialising it."""
+        if head_mask is not None or output_attentions:
+            raise NotImplementedError("head_mask / output_attentions are not supported by the fused attention kernel")
+        exp = self.config.max_source_positions * 2
+        if input_features.shape[-1] != exp:
+            raise ValueError(f"Qwen2Audio expects the mel input features to be of length {exp}, but found "
+                             f"{input_features.shape[-1]}. Make sure to pad the input mel features to {exp}.")
+        x = input_features.to(device=self.device)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        mel_btc = ops.transpose_cast(x.contiguous(), self.dtype)
+        if feat_len is None and attention_mask is not None:
+            feat_len = (attention_mask[:, 0, 0, :] == 0).sum(-1)
+        out = self.encode_btc(mel_btc, feat_len)
+        if return_dict is False:
+            return (out,)
+        return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)

@@ -46,12 +46,16 @@ const char* afhip_last_error(void);
  *   wav      [B, n_samples] f32, n_samples <= 480000 (shorter clips are zero-padded on the fly, :1056-1057)
  *   mel_out  layout 0: [B,128,3000] (extractor layout)   layout 1: [B,3000,128] (preprocess / encode_batch layout)
  *            out_dtype AFHIP_F32 or AFHIP_BF16 (the cast scripts/inference.py:272 applies)
- *   filters  [201,128] f32 mel filter bank (transformers/audio_utils.py:638-729), window [400] f32 periodic Hann
+ *   tables   device copy of the constant block afhip_log_mel_tables_host() builds on the host from the
+ *            [201,128] f32 mel filter bank (transformers/audio_utils.py:638-729): folded-DFT cos/sin tables,
+ *            periodic Hann window, filter bands
  *   workspace >= afhip_log_mel_workspace_bytes(B)
  */
+size_t afhip_log_mel_tables_bytes(void);
+int afhip_log_mel_tables_host(void* host_buf, const float* filters_host);
 size_t afhip_log_mel_workspace_bytes(int B);
 int afhip_log_mel(const float* wav, int B, int n_samples, int wav_stride, void* mel_out, int layout, int out_dtype,
-                  const float* filters, const float* window, void* workspace, void* stream);
+                  const float* tables, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T): the arithmetic of every nn.Linear / nn.Conv1d on the path
@@ -73,6 +77,7 @@ typedef struct {
     int act;
     int res_row_mod;
     int conv_Tin, conv_Tout, conv_stride, conv_C;
+    int out_f32; /* store C as f32 whatever `dtype` is (logits) */
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 

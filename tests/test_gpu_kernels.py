@@ -241,3 +241,43 @@ def test_rope_cache_causal_attention(dt, nq, nkv, hd):
         ref = _ref_attention(qr, kall, vall, causal=True, q_pos0=pos0)
         _check(out, ref, *_tol(dt, (2e-5, 1e-4), (2e-2, 2e-2)), f"causal attention pos0={pos0}")
         pos0 += stepT
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (8, 1000, 3584), (16, 8200, 768), (33, 9000, 1280), (64, 256, 3072)])
+def test_gemm_skinny(dt, M, N, K):
+    """decode-shape GEMM (weight streaming, split-K over 8 waves) incl. bias/residual and f32 logits output."""
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    ad, af = _q(_rand(M, K, seed=31), dt)
+    wd, wf = _q(_rand(N, K, seed=32, scale=0.05), dt)
+    bd, bf = _q(_rand(N, seed=33, scale=0.1), dt)
+    rd, rf = _q(_rand(M, N, seed=34), dt)
+    for out_f32 in (0, 1):
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else dt, device=_dev())
+        g = L.GemmArgs()
+        g.A, g.W, g.bias, g.residual, g.C = ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldw, g.ldc, g.ldres = M, N, K, K, K, N, N
+        g.dtype, g.act, g.out_f32 = L.dtype_code(dt), 0, out_f32
+        L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+        ref = af @ wf.T + bf + rf
+        tol = (2e-5, 2e-5) if (dt == torch.float32 or out_f32) and dt == torch.float32 else ((1e-4, 1e-4) if out_f32 else (2e-2, 2e-2))
+        _check(out, ref, *tol, f"skinny {M}x{N}x{K} out_f32={out_f32}")
+
+
+def test_masked_argmax_first_index_ties():
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    V = 5000
+    x = _rand(3, V, seed=35)
+    x[0, 700] = 9.0; x[0, 4100] = 9.0; x[0, 10] = 50.0          # 10 is outside the allowed set
+    x[1, 2] = 7.0; x[1, 3] = 7.0                                   # tie inside the first interval
+    x[2, :] = -float("inf"); x[2, 4500] = -3.0
+    iv = torch.tensor([[2, 4], [256, 4800]], dtype=torch.int32)
+    tok = torch.zeros(3, dtype=torch.int64, device=_dev())
+    L.check(lib.afhip_masked_argmax(L.ptr(x.to(_dev())), 3, V, L.ptr(iv.to(_dev())), 2, L.ptr(tok), L.stream_ptr()))
+    mask = torch.ones(V, dtype=torch.bool); mask[2:4] = False; mask[256:4800] = False
+    ref = x.masked_fill(mask[None], float("-inf")).argmax(-1)
+    assert tok.cpu().tolist() == ref.tolist() == [700, 2, 4500]
