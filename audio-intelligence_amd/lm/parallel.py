@@ -1,0 +1,494 @@
+"""ParallelLLM on MI355X: the UALM multi-stream LLM wrapper (Qwen2 backbone) over the HIP library.
+
+Host-side mirror of `ParallelHFModel` / `ParallelLLM` (UALM/models/ualm/lm/parallel.py:17-646) for the
+audio-understanding inference path: same factory arguments, same state-dict keys (HF Qwen2 names under `model.`,
+`lm_head`, `stream_emb`, `adaptor.<io>`, `multimodal_io_dict.<io>.model.*`), same methods (`prepare_inference`,
+`inference`, `inference_segment`, `_embed`, `_step`, `_logits_to_token`) and buffers.  All arithmetic runs in
+csrc/ (llm.hip); the KV cache is a preallocated [layer,B,kv_head,cap,hd] buffer instead of DynamicCache, and
+greedy decode keeps token selection and the eos/eot bookkeeping on the device (no per-token host sync).
+Training (`forward` / `_loss`, lm/parallel.py:176-217,286-384) is out of scope.
+"""
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..multimodal_io.modeling_whisper import _Linear, _Norm, _Embedding
+
+
+def ParallelHFModel(model_hf_tag, **kwargs):
+    """Factory with the reference's signature (lm/parallel.py:17-28); `model_hf_tag` is a local directory."""
+    return ParallelLLM.from_pretrained(model_hf_tag, **kwargs)
+
+
+class KVCache:
+    """Preallocated key/value store [n_layers, B, n_kv, cap, hd]; `length` = valid positions."""
+
+    def __init__(self, n_layers, B, n_kv, cap, hd, dtype, device):
+        self.k = torch.zeros((n_layers, B, n_kv, cap, hd), dtype=dtype, device=device)
+        self.v = torch.zeros_like(self.k)
+        self.length = 0
+
+    @property
+    def cap(self):
+        return self.k.shape[3]
+
+    @property
+    def batch(self):
+        return self.k.shape[1]
+
+    def get_seq_length(self):
+        return self.length
+
+    def reserve(self, cap):
+        if cap <= self.cap:
+            return
+        cap = (cap + 63) // 64 * 64
+        for name in ("k", "v"):
+            old = getattr(self, name)
+            new = torch.zeros(old.shape[:3] + (cap, old.shape[4]), dtype=old.dtype, device=old.device)
+            new[:, :, :, : self.length] = old[:, :, :, : self.length]
+            setattr(self, name, new)
+
+    def batch_select_indices(self, indices):
+        self.k = self.k[:, indices].contiguous()
+        self.v = self.v[:, indices].contiguous()
+
+    def struct(self):
+        s = L.KvCache()
+        s.k, s.v, s.cap, s.B = self.k.data_ptr(), self.v.data_ptr(), self.cap, self.batch
+        return s
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, H, nq, nkv, hd):
+        super().__init__()
+        self.q_proj = _Linear(H, nq * hd)
+        self.k_proj = _Linear(H, nkv * hd)
+        self.v_proj = _Linear(H, nkv * hd)
+        self.o_proj = _Linear(nq * hd, H, bias=False)
+
+
+class _MLP(nn.Module):
+    def __init__(self, H, I):
+        super().__init__()
+        self.gate_proj = _Linear(H, I, bias=False)
+        self.up_proj = _Linear(H, I, bias=False)
+        self.down_proj = _Linear(I, H, bias=False)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, H, nq, nkv, hd, I):
+        super().__init__()
+        self.self_attn = _SelfAttn(H, nq, nkv, hd)
+        self.mlp = _MLP(H, I)
+        self.input_layernorm = _Norm(H, bias=False)
+        self.post_attention_layernorm = _Norm(H, bias=False)
+
+
+class _Backbone(nn.Module):
+    def __init__(self, cfg, vocab_size):
+        super().__init__()
+        H = cfg["hidden_size"]
+        nq, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        hd = cfg.get("head_dim") or H // nq
+        self.embed_tokens = _Embedding(vocab_size, H)
+        self.layers = nn.ModuleList([_DecoderLayer(H, nq, nkv, hd, cfg["intermediate_size"]) for _ in range(cfg["num_hidden_layers"])])
+        self.norm = _Norm(H, bias=False)
+
+
+class ParallelLLM(nn.Module):
+    """Parallel multimodal LLM supporting multi-stream token processing (inference path)."""
+
+    def __init__(self, config: dict, multimodal_io: dict, vocab: List[str], vocab_intervals: Dict[str, list]):
+        super().__init__()
+        if config.get("architectures", ["Qwen2ForCausalLM"])[0] != "Qwen2ForCausalLM":
+            raise NotImplementedError(f"architecture {config.get('architectures')} not supported (Qwen2ForCausalLM only)")
+        self.config = SimpleNamespace(**config)
+        self.cfg = config
+        vocab_size = max(end for iv in vocab_intervals.values() for _, end in iv)      # lm/parallel.py:84-90
+        H = config["hidden_size"]
+        self.model = _Backbone(config, vocab_size)
+        self.lm_head = _Linear(H, vocab_size, bias=False)
+        streams = [io.num_stream() for io in multimodal_io.values() if io.is_discrete]
+        if len(streams) == 0:
+            raise ValueError("Cannot proceed with all IOs being continuous")
+        self.num_stream = max(streams)
+        self.stream_emb = _Embedding(self.num_stream, H)
+        self.multimodal_io_dict = nn.ModuleDict(multimodal_io)
+        self.adaptor = nn.ModuleDict()
+        for io_name, io in self.multimodal_io_dict.items():
+            if not io.is_discrete:
+                self.adaptor[io_name] = _Linear(io.feature_dim(), H)
+        self.vocab = vocab
+        self.vocab_intervals = vocab_intervals
+        self._packed = None
+        self._ws = None
+        self._allowed = {}
+
+    # ---------------------------------------------------------------- construction
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, multimodal_io, vocab, vocab_intervals,
+                        max_loss_interval: int = 13192, **kwargs):
+        """lm/parallel.py:51-174.  Reads config.json from a local directory; if base-LLM weights are present
+        (model.safetensors with HF Qwen2 names) the text rows of the rebuilt embedding / lm_head tables are
+        filled from them (:98-128); everything else is then expected from the UALM checkpoint
+        (`load_state_dict(torch.load(...)["module"], strict=True)`, scripts/inference.py:150-152)."""
+        with open(os.path.join(pretrained_model_name_or_path, "config.json")) as f:
+            cfg = json.load(f)
+        if "rope_theta" not in cfg and isinstance(cfg.get("rope_parameters"), dict):
+            cfg["rope_theta"] = cfg["rope_parameters"].get("rope_theta", 10000.0)
+        model = cls(cfg, multimodal_io, vocab, vocab_intervals)
+        with torch.no_grad():   # defaults for anything a checkpoint does not overwrite (lm/parallel.py:93-96,138)
+            for n, p in model.named_parameters():
+                if n.startswith("multimodal_io_dict."):
+                    continue
+                if n.endswith("bias"):
+                    p.zero_()
+                elif p.dim() == 1:
+                    p.fill_(1.0)
+                elif n in ("model.embed_tokens.weight", "stream_emb.weight"):
+                    p.normal_(0.0, 1.0)
+                else:
+                    p.normal_(0.0, 0.02)
+            model.model.embed_tokens.weight[0] = 0.0
+            model.lm_head.weight[0] = 0.0
+        st = os.path.join(pretrained_model_name_or_path, "model.safetensors")
+        if os.path.exists(st) and "text" in vocab_intervals:
+            from safetensors.torch import load_file
+            base = load_file(st)
+            ts, te = vocab_intervals["text"][0]
+            if te - ts != base["model.embed_tokens.weight"].shape[0]:
+                raise ValueError(f"text_end - text_start ({te - ts}) must equal original vocab size ({base['model.embed_tokens.weight'].shape[0]})")
+            own = model.state_dict()
+            with torch.no_grad():
+                for k, v in base.items():
+                    if k == "model.embed_tokens.weight":
+                        own[k][ts:te] = v
+                    elif k == "lm_head.weight":
+                        own[k][ts:te] = v
+                    elif k in own:
+                        own[k].copy_(v)
+        dt = kwargs.get("dtype", kwargs.get("torch_dtype"))
+        if dt is not None:
+            model = model.to(dt)
+        return model
+
+    def _apply(self, fn, *a, **kw):
+        self._packed = None
+        self._ws = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._packed = None
+        return super().load_state_dict(*a, **kw)
+
+    @property
+    def dtype(self):
+        return self.lm_head.weight.dtype
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    # ---------------------------------------------------------------- packing for the HIP library
+    def pack(self, max_positions: Optional[int] = None):
+        if self._packed is not None and (max_positions is None or max_positions <= self._packed.max_pos):
+            return self._packed
+        cfg = self.cfg
+        dev, dt = self.device, self.dtype
+        if dev.type != "cuda":
+            raise L.AfhipError("ParallelLLM runs on the GPU only: call .to('cuda') first (no CPU fallback)")
+        H, nq, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        hd = cfg.get("head_dim") or H // nq
+        I = cfg["intermediate_size"]
+        max_pos = max(max_positions or 0, 4096)
+        keep = []
+
+        def P(t):
+            t = t.detach().contiguous()
+            keep.append(t)
+            return t
+
+        w = L.LlmWeights()
+        w.hidden, w.n_layers, w.n_q, w.n_kv, w.hd, w.inter = H, cfg["num_hidden_layers"], nq, nkv, hd, I
+        w.vocab, w.n_stream, w.rms_eps, w.dtype = self.lm_head.weight.shape[0], self.num_stream, float(cfg.get("rms_norm_eps", 1e-6)), L.dtype_code(dt)
+        w.embed = P(self.model.embed_tokens.weight).data_ptr()
+        names = ["ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gu_w", "down_w"]
+        lists = {n: [] for n in names}
+        for lyr in self.model.layers:
+            a, m = lyr.self_attn, lyr.mlp
+            lists["ln1_w"].append(P(lyr.input_layernorm.weight))
+            lists["qkv_w"].append(P(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)))
+            lists["qkv_b"].append(P(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0)))
+            lists["o_w"].append(P(a.o_proj.weight))
+            lists["ln2_w"].append(P(lyr.post_attention_layernorm.weight))
+            g, u = m.gate_proj.weight, m.up_proj.weight
+            lists["gu_w"].append(P(torch.stack([g.view(I // 32, 32, H), u.view(I // 32, 32, H)], dim=1).reshape(2 * I, H)))
+            lists["down_w"].append(P(m.down_proj.weight))
+        arrays = {}
+        for n in names:
+            arrays[n] = L.ptr_array(lists[n])
+            setattr(w, n, C.cast(arrays[n], L.c_void_pp))
+        w.norm_w = P(self.model.norm.weight).data_ptr()
+        w.lm_head = P(self.lm_head.weight).data_ptr()
+        w.stream_emb = P(self.stream_emb.weight).data_ptr()
+        # rotary tables exactly as transformers computes them (modeling_qwen2.py:91-103,110-121): f32 on the host
+        theta = float(cfg.get("rope_theta", 10000.0))
+        inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+        fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
+        cos, sin = P(fr.cos().to(dev)), P(fr.sin().to(dev))
+        w.rope_cos, w.rope_sin, w.rope_max_pos = cos.data_ptr(), sin.data_ptr(), max_pos
+        self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv)
+        return self._packed
+
+    def _workspace(self, B, T):
+        lib = L.lib()
+        need = lib.afhip_llm_workspace_bytes(C.byref(self.pack().w), B, T)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def new_cache(self, B, cap):
+        pk = self.pack(cap)
+        return KVCache(self.cfg["num_hidden_layers"], B, pk.nkv, (cap + 63) // 64 * 64, pk.hd, self.dtype, self.device)
+
+    # ---------------------------------------------------------------- inference logic (lm/parallel.py:386-644)
+    def prepare_inference(self):
+        """lm/parallel.py:535-568: special-token tensors, modality mask, per-IO restricted-decoding masks."""
+        for token in ["assistant", "audio", "text", "eos", "eot"]:
+            token_tensor = torch.zeros((1, 1, self.num_stream)).long()
+            token_tensor[0, 0, 0] = self.vocab.index(f"<|{token}|>")
+            self.register_buffer(f"{token}_token", token_tensor.to(self.device))
+        mask = torch.ones(self.num_stream, len(self.vocab)).bool()
+        for token in ["audio", "text", "image", "video", "toolcall"]:
+            mask[0, self.vocab.index(f"<|{token}|>")] = False
+        mask[1:, 0] = False
+        self.register_buffer("modality_mask", mask[None, None].to(self.device))
+        self.eot_token_id = self.vocab.index("<|eot|>")
+        self.eos_token_id = self.vocab.index("<|eos|>")
+        for io_name, intervals in self.vocab_intervals.items():
+            mask = torch.ones(self.num_stream, len(self.vocab)).bool()
+            for idx, (start, end) in enumerate(intervals):
+                mask[idx, start:end] = False
+            for idx in range(len(intervals), self.num_stream):
+                mask[idx, 0] = False
+            mask[0, self.eot_token_id] = False
+            mask[0, self.eos_token_id] = False
+            io_name = "audio" if io_name == "discrete_audio" else io_name
+            self.register_buffer(f"{io_name}_mask", mask[None, None].to(self.device))
+        self._allowed = {}
+
+    def _allowed_intervals(self, name: str):
+        """Stream-0 allowed id runs of a mask buffer as a device int32 [n,2] tensor, plus whether every other
+        stream may only emit pad (then the device-side greedy loop is exact)."""
+        if name not in self._allowed:
+            m = getattr(self, f"{name}_mask")[0, 0].cpu()
+            ok = (~m[0]).to(torch.int8)
+            d = torch.diff(torch.cat([torch.zeros(1, dtype=torch.int8), ok, torch.zeros(1, dtype=torch.int8)]))
+            starts, ends = (d == 1).nonzero().flatten(), (d == -1).nonzero().flatten()
+            iv = torch.stack([starts, ends], dim=1).to(torch.int32)
+            pad_only = bool(((~m[1:]).sum(-1) == 1).all() and (~m[1:, 0]).all()) if self.num_stream > 1 else True
+            self._allowed[name] = (iv.to(self.device).contiguous(), pad_only)
+        return self._allowed[name]
+
+    @torch.no_grad()
+    def _embed(self, input_ids, kwargs):
+        """lm/parallel.py:219-284: stream-summed token embeddings, continuous features spliced in through the adaptor."""
+        for io_name, io in self.multimodal_io_dict.items():
+            if io.is_discrete and f"{io_name}_feats" in kwargs:
+                raise NotImplementedError("on-the-fly discrete tokenisation (lm/parallel.py:235-257) is outside the audio-understanding path")
+        input_embeds = ops.embed_sum(input_ids.to(self.device), self.model.embed_tokens.weight)
+        for io_name, io in self.multimodal_io_dict.items():
+            if io.is_discrete:
+                continue
+            if f"{io_name}_indices" not in kwargs or f"{io_name}_feats" not in kwargs or f"{io_name}_lengths" not in kwargs:
+                continue
+            feats = io.encode_batch(kwargs[f"{io_name}_feats"], kwargs[f"{io_name}_lengths"])
+            ad = self.adaptor[io_name]
+            for feat, (bidx, start, length) in zip(feats, kwargs[f"{io_name}_indices"].tolist()):
+                n = min(length, feat.shape[0])
+                ops.gemm(feat[:n], ad.weight, bias=ad.bias, out=input_embeds[bidx, start:start + n])
+        return input_embeds
+
+    @torch.no_grad()
+    def _forward_hidden(self, input_embeds, cache: Optional[KVCache]):
+        lib = L.lib()
+        B, T, H = input_embeds.shape
+        if cache is None:
+            cache = self.new_cache(B, T + 64)
+        pos0 = cache.length
+        cache.reserve(pos0 + T)
+        pk = self.pack(cache.cap)
+        x = input_embeds.to(self.dtype).contiguous()
+        hid = torch.empty_like(x)
+        ws = self._workspace(B, T)
+        cs = cache.struct()
+        L.check(lib.afhip_llm_forward(C.byref(pk.w), L.ptr(x), B, T, pos0, C.byref(cs), L.ptr(hid), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        cache.length = pos0 + T
+        return hid, cache
+
+    @torch.no_grad()
+    def _step(self, input_ids=None, input_embeds=None, past_key_values=None, mask=None):
+        """lm/parallel.py:570-597 -> (logits [B,T,S,V], cache)."""
+        assert (input_ids is None) != (input_embeds is None), "Either input_ids or input_embeds should be None"
+        lib = L.lib()
+        if input_ids is not None:
+            assert input_ids.size(2) == self.num_stream
+            input_embeds = ops.embed_sum(input_ids.to(self.device), self.model.embed_tokens.weight)
+        hid, cache = self._forward_hidden(input_embeds, past_key_values)
+        B, T, H = hid.shape
+        S, V = self.num_stream, self.lm_head.weight.shape[0]
+        logits = torch.empty((B, T, S, V), dtype=torch.float32, device=self.device)
+        need = B * T * S * H * hid.element_size() + 256
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hid), B * T, S, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        logits = logits.to(self.dtype)
+        if mask is not None:
+            logits.masked_fill_(mask, float("-inf"))
+        return logits, cache
+
+    def _logits_to_token(self, logits, temperature, topk):
+        """lm/parallel.py:599-608."""
+        if temperature == 0:
+            return logits.argmax(-1)
+        topk_values, topk_indices = torch.topk(logits, topk)
+        probs = torch.softmax(topk_values.float() / temperature, dim=-1)
+        inner = torch.multinomial(probs.flatten(end_dim=-2), num_samples=1).view(probs[..., :1].size())
+        return torch.gather(topk_indices, -1, inner).squeeze(-1)
+
+    @torch.no_grad()
+    def _greedy_device_loop(self, modality_token, cache: KVCache, modality: str, max_step: int, poll: int = 16):
+        """Device-resident greedy loop: one `afhip_llm_decode_step` per token, eos/eot bookkeeping on the GPU, the
+        host looks at the finished flags every `poll` steps only.  Exact w.r.t. lm/parallel.py:480-513 when every
+        stream but 0 can only emit pad."""
+        lib = L.lib()
+        B = cache.batch
+        iv, _ = self._allowed_intervals(modality)
+        T0 = cache.length
+        cache.reserve(T0 + max_step + 2)
+        pk = self.pack(cache.cap)
+        prev = modality_token[:, 0, 0].to(self.device).contiguous().clone()
+        out_tokens = torch.zeros((max_step, B), dtype=torch.int64, device=self.device)
+        finished = torch.full((B,), -1, dtype=torch.int32, device=self.device)
+        st = L.DecodeState()
+        st.prev_token, st.out_tokens, st.finished_at = prev.data_ptr(), out_tokens.data_ptr(), finished.data_ptr()
+        st.allowed, st.n_iv, st.eos_id, st.eot_id = iv.data_ptr(), iv.shape[0], self.eos_token_id, self.eot_token_id
+        ws = self._workspace(B, 1)
+        cs = cache.struct()
+        n_done = max_step
+        for step in range(max_step):
+            L.check(lib.afhip_llm_decode_step(C.byref(pk.w), C.byref(cs), C.byref(st), B, T0 + step, step, L.ptr(ws), ws.numel(), L.stream_ptr()))
+            if (step + 1) % poll == 0 or step == max_step - 1:
+                f = finished.cpu()
+                if bool((f >= 0).all()):
+                    n_done = int(f.max()) + 1      # the reference leaves the loop right after this step (:512-513)
+                    break
+        cache.length = T0 + n_done
+        f = finished.cpu()
+        finish_idx = torch.where(f < 0, torch.full_like(f, n_done - 1), f)
+        hypos = torch.zeros((B, n_done, self.num_stream), dtype=torch.int64, device=self.device)
+        hypos[:, :, 0] = out_tokens[:n_done].t()
+        return hypos, finish_idx, cache
+
+    @torch.no_grad()
+    def inference_segment(self, config: dict, cache=None, enforce_modality: str = None, **kwargs):
+        """lm/parallel.py:428-533."""
+        input_ids = kwargs.get("seqs").to(self.device)
+        B0 = input_ids.shape[0]
+        input_ids = torch.cat([input_ids, self.assistant_token.expand(B0, -1, -1)], dim=1)
+        device = input_ids.device
+        input_embeds = self._embed(input_ids, kwargs)
+
+        # (1) prefill; only the last position's stream-0 logits are consumed (:447-457)
+        hid, cache = self._forward_hidden(input_embeds, cache)
+        if enforce_modality is not None:
+            modality_token = getattr(self, f"{enforce_modality}_token").expand(B0, -1, -1).clone()
+        else:
+            lib = L.lib()
+            iv, _ = self._allowed_intervals("modality")
+            last = hid[:, -1].contiguous()
+            logits = torch.empty((B0, self.lm_head.weight.shape[0]), dtype=torch.float32, device=device)
+            ws = torch.empty(B0 * hid.shape[-1] * hid.element_size() + 256, dtype=torch.uint8, device=device)
+            L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(last), B0, 1, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+            tok = torch.empty(B0, dtype=torch.int64, device=device)
+            L.check(lib.afhip_masked_argmax(L.ptr(logits), B0, logits.shape[1], L.ptr(iv), iv.shape[0], L.ptr(tok), L.stream_ptr()))
+            modality_token = torch.zeros((B0, 1, self.num_stream), dtype=torch.int64, device=device)
+            modality_token[:, 0, 0] = tok
+
+        # (2) modality and its mask
+        modality = self.vocab[modality_token.flatten()[0].item()].replace("<|", "").replace("|>", "")
+        if not hasattr(self, f"{modality}_mask"):
+            raise ValueError(f"Try to predict {modality} modality But no decoding mask exists for it.")
+        modality_mask = getattr(self, f"{modality}_mask")
+        if modality not in config:
+            raise ValueError(f"Try to predict {modality} modality But the corresponding inference config is missing.")
+        this_config = config[modality]
+
+        num_hypo = config.get("num_hypo", 1)
+        if num_hypo > 1:
+            indices = torch.zeros(num_hypo).long().to(device)
+            cache.batch_select_indices(indices)
+            modality_token = modality_token.tile(num_hypo, 1, 1)
+        cfg = this_config.get("cfg", 1)
+        _, pad_only = self._allowed_intervals(modality)
+
+        if this_config["temperature"] == 0 and cfg <= 1 and pad_only:
+            hypos, finish_idx, cache = self._greedy_device_loop(modality_token, cache, modality, this_config["max_step"])
+            prev_token = hypos[:, -1:, :].clone()
+        else:
+            if cfg > 1:
+                raise NotImplementedError("classifier-free guidance decoding (lm/parallel.py:472-492,610-644) is the audio-output path: not built yet")
+            hyp_list = []
+            finish_idx = torch.ones(cache.batch).long().to(device) * -1
+            prev_token = modality_token
+            for step in range(this_config["max_step"]):
+                logits, cache = self._step(input_ids=prev_token, past_key_values=cache, mask=modality_mask)
+                prev_token = self._logits_to_token(logits, temperature=this_config["temperature"], topk=this_config["topk"])
+                hyp_list.append(prev_token)
+                finish_here = torch.logical_and(
+                    torch.logical_or(prev_token[:, 0, 0] == self.eot_token_id, prev_token[:, 0, 0] == self.eos_token_id),
+                    finish_idx == -1)
+                finish_idx = torch.where(finish_here, step, finish_idx)
+                if torch.all(finish_idx >= 0):
+                    break
+            finish_idx = torch.where(finish_idx == -1, step, finish_idx)
+            hypos = torch.cat(hyp_list, dim=1)
+
+        # (5) "prefill the last token" so that a following segment continues from it (:523-526)
+        prev_token = prev_token.clone()
+        prev_token[..., 1:] = 0
+        emb = ops.embed_sum(prev_token, self.model.embed_tokens.weight)
+        _, cache = self._forward_hidden(emb, cache)
+
+        hypo_lst = []
+        for idx, hypo in zip(finish_idx.tolist(), hypos):
+            hypo_lst.append((hypo[: idx + 1], modality))
+        return hypo_lst, cache
+
+    @torch.no_grad()
+    def inference(self, inference_config: dict, cache=None, **kwargs):
+        """lm/parallel.py:387-426."""
+        messages = []
+        while True:
+            decoded_sequences, cache = self.inference_segment(inference_config, cache=cache, enforce_modality=None, **kwargs)
+            for seq, modality in decoded_sequences:
+                if seq[-1, 0] == self.eos_token_id or seq[-1, 0] == self.eot_token_id:
+                    seq = seq[:-1]
+                io_name = "discrete_audio" if modality == "audio" else modality
+                seq = seq.unsqueeze(0) - self.vocab_intervals[io_name][0][0]
+                io = self.multimodal_io_dict[io_name]
+                lengths = torch.Tensor([seq.size(1)]).long().to(seq.device)
+                content = io.decode_batch(seq, lengths)
+                messages.append(["assistant", modality, content])
+            if len(decoded_sequences) > 1:
+                break
+            elif decoded_sequences[0][0][-1, 0] != self.eot_token_id:
+                break
+        return messages, cache
