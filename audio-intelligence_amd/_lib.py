@@ -78,6 +78,8 @@ SIGNATURES = {
     "afhip_log_mel": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "afhip_gemm": (_I, [C.POINTER(GemmArgs), _P]),
     "afhip_gemm_skinny": (_I, [C.POINTER(GemmArgs), _P]),
+    "afhip_prof_enable": (_I, [_I]),
+    "afhip_prof_collect": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "afhip_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "afhip_avgpool_ln": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "afhip_rmsnorm": (_I, [_P, _P, _P, _I, _I, _F, _I, _P]),

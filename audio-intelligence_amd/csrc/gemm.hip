@@ -6,6 +6,7 @@
 // Register-prefetched double-buffered LDS, one barrier per K tile.  Optional implicit im2col on A (conv1d
 // k=3 pad=1, channel-last input) and fused epilogues: bias, erf-GELU, SwiGLU pair, residual / position table.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -206,6 +207,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
 }  // namespace
 
+// ---- optional in-library timing of this kernel (bench.py roofline leg): HIP events on the launch stream ----
+namespace {
+struct GemmProf {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;      // 2 per launch
+    double* flops = nullptr;
+    int* dtype = nullptr;
+} g_prof;
+}  // namespace
+
+extern "C" int afhip_prof_enable(int max_launches) {
+    AFHIP_CHECK(max_launches > 0, "afhip_prof_enable: bad capacity");
+    if (g_prof.cap < max_launches) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        free(g_prof.ev); free(g_prof.flops); free(g_prof.dtype);
+        g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_launches);
+        g_prof.flops = (double*)malloc(sizeof(double) * max_launches);
+        g_prof.dtype = (int*)malloc(sizeof(int) * max_launches);
+        for (int i = 0; i < 2 * max_launches; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) { afhip_set_error("afhip_prof_enable: hipEventCreate failed"); return AFHIP_ERR_LAUNCH; }
+        g_prof.cap = max_launches;
+    }
+    g_prof.n = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+// Waits for the recorded events; returns launches / summed milliseconds / summed algorithmic FLOPs (2MNK) of
+// the afhip_gemm launches of `dtype` since afhip_prof_enable, and switches recording off.
+extern "C" int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops) {
+    AFHIP_CHECK(n_launches && total_ms && total_flops, "afhip_prof_collect: null pointer");
+    g_prof.on = false;
+    *n_launches = 0; *total_ms = 0.0; *total_flops = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (g_prof.dtype[i] != dtype) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
+            afhip_set_error("afhip_prof_collect: event query failed");
+            return AFHIP_ERR_LAUNCH;
+        }
+        *n_launches += 1; *total_ms += ms; *total_flops += g_prof.flops[i];
+    }
+    return 0;
+}
+
 extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_gemm: null args");
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_gemm: bad dtype %d", a->dtype);
@@ -247,10 +294,19 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(nwg < (1ll << 31), "afhip_gemm: grid too large");
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
+    const bool rec = g_prof.on && g_prof.n < g_prof.cap;
+    const int slot = g_prof.n;
+    if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
     if (a->dtype == AFHIP_BF16)
         hipLaunchKernelGGL(gemm_kernel<bf16>, dim3((unsigned)nwg), dim3(256), lds, s, p);
     else
         hipLaunchKernelGGL(gemm_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, s, p);
+    if (rec) {
+        (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+        g_prof.flops[slot] = 2.0 * (double)a->M * (double)a->N * (double)a->K;
+        g_prof.dtype[slot] = a->dtype;
+        g_prof.n = slot + 1;
+    }
     AFHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Benchmark of the AF3 / UALM audio-understanding hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Headline workload (BASELINE.json configs[1]): AF-Whisper encoder only -- log-mel + 32-layer encoder, batch = 32 clips
+of 30 s @ 16 kHz per GPU, bf16 storage / f32 accumulate, synthetic audio and seeded random weights of the true shape.
+One step = one pass of the hot path over one batch whose waveforms are already resident in HBM.  Clips are
+independent (the reference shards them `samples[rank::world_size]` with no communication, dataloader/dataset.py:80),
+so N GPUs = N replicas of the same per-GPU batch: weak scaling, no data-path collective.
+
+Rank 0 prints ONE JSON line: the bench contract + `roofline` (dominant kernel = the bf16 MFMA GEMM, timed live with
+HIP events inside the timed region), `cpu_baseline` (the CPU oracle timed on this host, N=1 only), plus the log-mel
+kernel's HBM figure and an AF3-7B-shape greedy-decode leg (decode tokens/s, the second half of BASELINE's metric).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from audio_intelligence_amd import _lib as L  # noqa: E402
+from audio_intelligence_amd.utils import synthetic as syn  # noqa: E402
+from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig  # noqa: E402
+from audio_intelligence_amd.multimodal_io.feature_extraction import WhisperFeatureExtractorHIP  # noqa: E402
+
+ENC_CFG = dict(num_mel_bins=128, d_model=1280, encoder_attention_heads=20, encoder_ffn_dim=5120, encoder_layers=32,
+               max_source_positions=1500)
+LLM_7B = dict(architectures=["Qwen2ForCausalLM"], hidden_size=3584, num_hidden_layers=28, num_attention_heads=28,
+              num_key_value_heads=4, intermediate_size=18944, rope_theta=1e6, rms_norm_eps=1e-6, vocab_size=152064)
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
+MEL_BYTES_PER_CLIP = 480000 * 4 + 128 * 3000 * 4      # read wav + write f32 mel
+
+
+def enc_flops_per_clip(c):
+    d, f, Lr, T = c["d_model"], c["encoder_ffn_dim"], c["encoder_layers"], c["max_source_positions"]
+    stem = 2 * 3000 * d * 3 * c["num_mel_bins"] + 2 * T * d * 3 * d
+    return float(stem + Lr * (8 * T * d * d + 4 * T * T * d + 4 * T * d * f))
+
+
+def build_encoder(device, dtype, cpu_state=None):
+    enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(ENC_CFG))
+    if cpu_state is not None:
+        enc.load_state_dict(cpu_state, strict=True)
+        return enc.to(device, dtype)
+    enc = enc.to(device, dtype)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            p.copy_(syn.synth_tensor(n, p.shape, 1, dtype=dtype, device=device))
+    return enc
+
+
+def cpu_baseline(cpu_state, n_clips, wav_cpu):
+    """The CPU oracle (build-owned PyTorch-CPU fp32 restatement, pinned to the reference by tests/golden) on a bounded
+    sample of the same workload."""
+    import oracle
+    threads = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    mel = oracle.logmel.log_mel(wav_cpu[:n_clips].numpy())
+    t_mel = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = oracle.afwhisper.encoder_forward(torch.from_numpy(mel), cpu_state, ENC_CFG)
+    t_enc = time.perf_counter() - t0
+    return {"value": n_clips * 30.0 / (t_mel + t_enc), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"{n_clips} of the 32 clips (log-mel {t_mel:.2f} s + encoder {t_enc:.2f} s, fp32, SDPA attention)"}, out
+
+
+def decode_leg(device, enc, fe, B, n_steps, warm):
+    """AF3-7B shape (Qwen2.5-7B backbone, 8 streams, V=160520): B x 30-s clips + 32 prompt ids, prefill, then greedy
+    decode with the device-resident loop.  Returns tokens/s and the HBM figure of the decode step."""
+    from audio_intelligence_amd.lm.parallel import ParallelLLM
+    from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+    from audio_intelligence_amd.multimodal_io.abs_io import AbsIO
+    from audio_intelligence_amd import ualm_job
+
+    class _Text(AbsIO):
+        def __init__(self):
+            super().__init__(modality="text", is_discrete=True)
+
+        def num_stream(self):
+            return 1
+
+        def get_vocabulary(self):
+            return [f"<text_{i}>" for i in range(LLM_7B["vocab_size"])]
+
+        def get_stream_interval(self):
+            return [(0, LLM_7B["vocab_size"])]
+
+    class _Audio(AbsIO):
+        def __init__(self):
+            super().__init__(modality="audio", is_discrete=True)
+
+        def num_stream(self):
+            return 8
+
+        def get_vocabulary(self):
+            return [f"<audio_{i}>" for i in range(8 * 1025)]
+
+        def get_stream_interval(self):
+            return [(s * 1025, (s + 1) * 1025) for s in range(8)]
+
+    cont = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="bfloat16", device=str(device), encoder=enc)
+    ios = {"text": _Text(), "discrete_audio": _Audio(), "continuous_audio": cont}
+    vocab, iv = ualm_job.build_vocabulary(ios)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(device):
+            model = ParallelLLM(LLM_7B, ios, vocab, iv)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if not n.startswith("multimodal_io_dict."):
+                p.copy_(syn.synth_tensor(n, p.shape, 2, dtype=torch.bfloat16, device=device))
+    model.prepare_inference()
+    model.eos_token_id = model.eot_token_id = -1           # random weights: never stop early
+    g = torch.Generator(device=device).manual_seed(99)
+    wav = torch.randn((B, 480000), generator=g, device=device) * 0.1
+    mel = fe.extract_device(wav, layout="btc", dtype=torch.bfloat16)
+    prompt = syn.make_prompt(LLM_7B["vocab_size"], 32)
+    S = 8
+    rows = [[1], [5], [7]] + [[256 + t] for t in prompt] + [[3], [5], [8]] + [[0]] * 750 + [[2]]
+    seq = torch.zeros((len(rows), S), dtype=torch.int64)
+    seq[:, 0] = torch.tensor([r[0] for r in rows])
+    start = 3 + len(prompt) + 3
+    batch = {"seqs": seq[None].repeat(B, 1, 1).to(device), "continuous_audio_feats": mel,
+             "continuous_audio_lengths": torch.full((B,), 3000, dtype=torch.long),
+             "continuous_audio_indices": torch.tensor([[b, start, 750] for b in range(B)])}
+    ids = torch.cat([batch["seqs"], model.assistant_token.expand(B, -1, -1)], dim=1)
+    T = ids.shape[1]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = model._embed(ids, batch)
+    hid, cache = model._forward_hidden(emb, model.new_cache(B, T + n_steps + warm + 8))
+    torch.cuda.synchronize()
+    t_prefill = time.perf_counter() - t0
+    tok = model.text_token.expand(B, -1, -1).clone()
+    hyp, _, cache = model._greedy_device_loop(tok, cache, "text", warm, poll=10 ** 9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hyp, _, cache = model._greedy_device_loop(hyp[:, -1:, :], cache, "text", n_steps, poll=10 ** 9)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    H, I, nl = LLM_7B["hidden_size"], LLM_7B["intermediate_size"], LLM_7B["num_hidden_layers"]
+    kvw = LLM_7B["num_key_value_heads"] * (H // LLM_7B["num_attention_heads"])
+    w_bytes = nl * 2 * (H * H * 2 + 2 * H * kvw + 3 * H * I) + 2 * len(vocab) * H
+    ctx = T + warm + n_steps // 2
+    step_bytes = w_bytes + B * ctx * nl * 2 * kvw * 2
+    gbs = step_bytes * n_steps / dt / 1e9
+    del model
+    return {"model": "AF3-7B shape (Qwen2.5-7B backbone, 8 streams, V=%d), random bf16 weights" % len(vocab),
+            "batch": B, "prompt_tokens": T, "decode_steps": n_steps, "tokens_per_s": B * n_steps / dt,
+            "ms_per_step": dt / n_steps * 1e3, "prefill_s": t_prefill,
+            "prefill_audio_s_per_s": B * 30.0 / t_prefill,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": None, "bytes_per_step": step_bytes}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="30-s clips per GPU per step")
+    ap.add_argument("--no-decode", action="store_true", help="skip the AF3-7B decode leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-clips", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
+    lib = L.lib()
+
+    B, dtype = args.batch, torch.bfloat16
+    fe = WhisperFeatureExtractorHIP()
+    do_cpu = (rank == 0 and world == 1 and not args.no_cpu)
+    cpu_state = syn.synth_state_dict(syn.encoder_param_shapes(ENC_CFG), 1) if do_cpu else None
+    enc = build_encoder(device, dtype, cpu_state)
+    wav_cpu = None
+    if do_cpu:
+        wav_cpu = torch.stack([torch.from_numpy(syn.make_wav(2000 + i, 480000)) for i in range(B)])
+        wav = wav_cpu.to(device)
+    else:
+        g = torch.Generator(device=device).manual_seed(2000 + rank)
+        wav = torch.randn((B, 480000), generator=g, device=device) * 0.1
+
+    mel_ws = torch.empty(lib.afhip_log_mel_workspace_bytes(B), dtype=torch.uint8, device=device)
+
+    def step():
+        mel = fe.extract_device(wav, layout="btc", dtype=dtype, workspace=mel_ws)
+        return enc.encode_btc(mel)
+
+    for _ in range(args.warmup):
+        out = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    L.check(lib.afhip_prof_enable(args.steps * (4 * ENC_CFG["encoder_layers"] + 2) + 8))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fence()
+    n_l, ms, fl = C.c_int(), C.c_double(), C.c_double()
+    L.check(lib.afhip_prof_collect(L.BF16, C.byref(n_l), C.byref(ms), C.byref(fl)))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-stage figures on this rank (outside the timed region) ----
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    n_mel = 20
+    ev0.record()
+    for _ in range(n_mel):
+        mel = fe.extract_device(wav, layout="btc", dtype=dtype, workspace=mel_ws)
+    ev1.record()
+    torch.cuda.synchronize()
+    mel_ms = ev0.elapsed_time(ev1) / n_mel
+    ev0.record()
+    for _ in range(3):
+        enc.encode_btc(mel)
+    ev1.record()
+    torch.cuda.synchronize()
+    enc_ms = ev0.elapsed_time(ev1) / 3
+
+    res = None
+    if rank == 0:
+        audio_s = world * args.steps * B * 30.0
+        gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        mel_gbs = MEL_BYTES_PER_CLIP * B / (mel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "audio-seconds encoded/sec (log-mel + AF-Whisper encoder)", "value": audio_s / elapsed, "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "AF-Whisper encoder only (BASELINE configs[1]): log-mel + 32-layer d=1280 encoder, "
+                                   "batch=32 x 30s@16kHz clips per GPU, wav resident in HBM",
+                       "batch_per_gpu": B, "clip_seconds": 30, "parallelism": f"clip-level replicas x{world} (no data-path collective)",
+                       "encoder_tflop_per_clip": enc_flops_per_clip(ENC_CFG) / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all encoder GEMMs incl. implicit-conv stem)",
+                         "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches": n_l.value, "avg_launch_ms": ms.value / max(1, n_l.value),
+                         "avg_launch_gflop": fl.value / max(1, n_l.value) / 1e9, "gemm_share_of_step": ms.value / (elapsed * 1e3) if world == 1 else None},
+            "stages": {"mel_ms": mel_ms, "mel_audio_s_per_s": B * 30.0 / (mel_ms * 1e-3),
+                       "mel_roofline": {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": mel_gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_clip": MEL_BYTES_PER_CLIP},
+                       "encoder_ms": enc_ms, "encoder_audio_s_per_s": B * 30.0 / (enc_ms * 1e-3),
+                       "encoder_tflops": enc_flops_per_clip(ENC_CFG) * B / (enc_ms * 1e-3) / 1e12},
+        }
+    if do_cpu:
+        cb, ref_out = cpu_baseline(cpu_state, args.cpu_clips, wav_cpu)
+        err = (out[: args.cpu_clips].float().cpu() - ref_out).abs()
+        cb["gpu_bf16_vs_cpu_fp32_max_abs_err"] = float(err.max())
+        cb["gpu_bf16_vs_cpu_fp32_mean_abs_err"] = float(err.mean())
+        res["cpu_baseline"] = cb
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if not args.no_decode:
+        del out
+        d = decode_leg(device, enc, fe, 8, 64, 8)
+        if dist is not None:
+            t = torch.tensor([d["tokens_per_s"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)        # replicas: whole-job tokens/s
+            d["tokens_per_s_all_gpus"] = float(t.item())
+        if rank == 0:
+            res["decode"] = d
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,12 @@ typedef struct {
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
+/* Measurement hook for bench.py's roofline leg: while enabled, every afhip_gemm launch is bracketed by HIP events on
+ * its own stream; collect() waits for them and returns the launch count, summed milliseconds and summed
+ * algorithmic FLOPs (2*M*N*K) of the launches of `dtype`, then disables recording. Not for production paths. */
+int afhip_prof_enable(int max_launches);
+int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops);
+
 /* Skinny GEMM for decode (M <= 64): weight-streaming, HBM-bound.  Same math as afhip_gemm, act NONE only. */
 int afhip_gemm_skinny(const afhip_gemm_args* args, void* stream);
 
