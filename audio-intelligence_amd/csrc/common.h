@@ -83,4 +83,19 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): one rcp, one exp, five FMAs -- the GEMM epilogue of the
+// throughput (bf16) path, where libm's erff would cost as many VALU cycles as the tile's MFMAs.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(e, x);
+}
+template <typename T> __device__ __forceinline__ float gelu_act(float x);
+template <> __device__ __forceinline__ float gelu_act<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_act<bf16>(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

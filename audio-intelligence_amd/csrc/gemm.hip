@@ -25,6 +25,7 @@ struct GemmP {
     int conv_Tin, conv_Tout, conv_stride, conv_C;
     int tiles_m, tiles_n;
     int out_f32;
+    int vec;   // 4-element vector epilogue allowed (alignment / range checked on the host)
 };
 
 // bijective XCD-aware remap of a linear workgroup id (blocks b and b+8 share an XCD under round-robin dispatch):
@@ -33,6 +34,96 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = id & 7, s = id >> 3;
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + s;
+}
+
+
+// Accumulator orientation: the MFMAs are issued as mma16(W fragment, X fragment), so a 32x32 accumulator tile has
+// the OUTPUT COLUMN n on its rows (registers) and the output row m on its lanes: lane (c = lane & 31, h = lane >> 5)
+// holds, for g = 0..3, the four consecutive columns n = 32 j + 8 g + 4 h + (0..3) of row m = 32 i + c.  Every store
+// is therefore a 4-element vector (8 B bf16 / 16 B f32) instead of a 2-byte scatter.
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16> { typedef bf16x4 type; };
+template <> struct Vec4<float> { typedef f32x4 type; };
+
+// Fused epilogue straight from registers: + bias -> act -> + residual (row m or m % res_row_mod) -> store as T (or
+// f32).  SWIGLU: tile column 0 holds the gate, column 1 the up projection of the same 32 outputs (32-row interleaved
+// weights); C is [M, N/2].  `vec` = every 4-group is in range and 4-element aligned (checked on the host).
+template <typename T, int MI, int NJ>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MI][NJ], int mbase, int nbase, int lane) {
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* C = reinterpret_cast<T*>(p.C);
+    const int fr = lane & 31, fh = lane >> 5;
+    typedef typename Vec4<T>::type V4;
+    if (p.act == AFHIP_ACT_SWIGLU) {
+        static_assert(NJ == 2, "SWIGLU epilogue pairs two tile columns");
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mbase + i * 32 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * fh;                 // column inside the 32-wide gate / up tile
+                if (nbase + nl >= p.N) continue;
+                V4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = from_f32<T>(silu(acc[i][0][4 * g + k]) * acc[i][1][4 * g + k]);
+                *reinterpret_cast<V4*>(C + (long long)m * p.ldc + (nbase >> 1) + nl) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 32 + fr;
+        if (m >= p.M) continue;
+        const long long rrow = (long long)(p.res_row_mod > 0 ? (m % p.res_row_mod) : m) * p.ldres;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = nbase + j * 32 + 8 * g + 4 * fh;
+                if (n0 >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
+                if (p.vec) {
+                    if (bias) {
+                        const V4 b4 = *reinterpret_cast<const V4*>(bias + n0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += to_f32<T>(b4[k]);
+                    }
+                    if (p.act == AFHIP_ACT_GELU) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = gelu_act<T>(v[k]);
+                    }
+                    if (res) {
+                        const V4 r4 = *reinterpret_cast<const V4*>(res + rrow + n0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += to_f32<T>(r4[k]);
+                    }
+                    if (p.out_f32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + n0) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        V4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = from_f32<T>(v[k]);
+                        *reinterpret_cast<V4*>(C + (long long)m * p.ldc + n0) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = n0 + k;
+                        if (n >= p.N) continue;
+                        float x = v[k] + (bias ? to_f32<T>(bias[n]) : 0.f);
+                        if (p.act == AFHIP_ACT_GELU) x = gelu_act<T>(x);
+                        if (res) x += to_f32<T>(res[rrow + n]);
+                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)m * p.ldc + n] = x;
+                        else C[(long long)m * p.ldc + n] = from_f32<T>(x);
+                    }
+                }
+            }
+    }
 }
 
 template <typename T>
@@ -144,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[j], fa[i], acc[i][j]);
         }
     };
 
@@ -161,48 +252,185 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         cur ^= 1;
     }
 
-    // ---- epilogue ----
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    T* C = reinterpret_cast<T*>(p.C);
-    if (p.act == AFHIP_ACT_SWIGLU) {
-        // wave's 64 N-rows = 32 gate rows (j=0) then 32 up rows (j=1) of the same 32 outputs
-        const int ncol = ((n0 + wn * 64) >> 1) + fr;
-        const bool nok = (n0 + wn * 64 + fr) < p.N;
+    epilogue<T, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass), two 64-KiB LDS stages, one barrier per K tile:
+//     top of iteration kt: vmcnt(0) + barrier   -> tile kt has landed for every wave, stage (kt+1)&1 is free
+//                          issue DMA of tile kt+1 into stage (kt+1)&1   (in flight during the MFMAs below)
+//                          MFMAs on stage kt&1
+// The LDS image is the same byte layout as above (128-B rows, 16-B chunk c of row r stored at slot c ^ (r & 7)).
+// An LDS-DMA wave-instruction writes 64 x 16 B linearly (= 8 whole rows), so the swizzle is applied on the SOURCE:
+// the lane that fills slot s of row r fetches chunk s ^ (r & 7).  Out-of-range conv taps read a zero page.
+__device__ __attribute__((aligned(16))) char g_zero_page[256];
+
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2_BYTES = BM2 * ROWB;   // 32 KiB per operand per stage
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
+    constexpr int SZ = sizeof(T);
+    constexpr int BK = ROWB / SZ;
+    constexpr int KC = BK / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // ---- DMA coordinates: pass i of wave w fills rows (i*8 + w)*8 .. +8 of a tile; lane -> (row, slot) ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int src_chunk = lslot ^ lrow;             // (row & 7) == lrow because pass bases are multiples of 8 rows
+    const char* a_ptr[4];
+    int a_ts[4];
+    const char* w_ptr[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                if (m < p.M && nok) {
-                    const float g = acc[i][0][e], u = acc[i][1][e];
-                    C[(long long)m * p.ldc + ncol] = from_f32<T>(silu(g) * u);
-                }
-            }
-        return;
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + lrow;
+        int m = m0 + row;
+        if (m > p.M - 1) m = p.M - 1;
+        if (p.conv_C > 0) {
+            const int b = m / p.conv_Tout, t = m - b * p.conv_Tout;
+            a_ts[i] = t * p.conv_stride - 1;
+            a_ptr[i] = p.A + ((long long)b * p.conv_Tin) * p.conv_C * SZ + src_chunk * 16;
+        } else {
+            a_ts[i] = 0;
+            a_ptr[i] = p.A + (long long)m * p.lda * SZ + src_chunk * 16;
+        }
+        int n = n0 + row;
+        if (n > p.N - 1) n = p.N - 1;
+        w_ptr[i] = p.W + (long long)n * p.ldw * SZ + src_chunk * 16;
     }
+    const int nk = p.K / BK;
+
+    auto dma_tile = [&](int kt, int buf) {
+        char* sa = smem + buf * 2 * TILE2_BYTES;
+        char* sw = sa + TILE2_BYTES;
+        const long long kbyte = (long long)kt * ROWB;
+        int tap = 0, c0 = 0;
+        if (p.conv_C > 0) {
+            const int k0 = kt * BK;
+            tap = k0 / p.conv_C;
+            c0 = k0 - tap * p.conv_C;
+        }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
-        if (n >= p.N) continue;
-        const float bv = bias ? to_f32<T>(bias[n]) : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int lds_off = (i * 8 + wave) * 1024;      // wave-uniform; the hardware adds lane * 16
+            const char* ga;
+            if (p.conv_C > 0) {
+                const int ts = a_ts[i] + tap;
+                ga = (ts >= 0 && ts < p.conv_Tin) ? a_ptr[i] + ((long long)ts * p.conv_C + c0) * SZ : g_zero_page + lslot * 16;
+            } else {
+                ga = a_ptr[i] + kbyte;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)(sa + lds_off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kbyte),
+                                             (__attribute__((address_space(3))) void*)(sw + lds_off), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                if (m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    if (p.act == AFHIP_ACT_GELU) v = gelu_erf(v);
-                    if (res) {
-                        const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-                        v += to_f32<T>(res[(long long)rm * p.ldres + n]);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    auto load_frag = [&](const char* base, int row, int kc) -> typename Frag8<T>::type {
+        if constexpr (SZ == 2) {
+            const int ch = kc * 2 + fh;
+            return *reinterpret_cast<const bf16x8*>(base + row * ROWB + ((ch ^ (row & 7)) << 4));
+        } else {
+            const int ch = kc * 4 + fh * 2;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(base + row * ROWB + ((ch ^ (row & 7)) << 4));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(base + row * ROWB + (((ch + 1) ^ (row & 7)) << 4));
+            return f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        }
+    };
+
+    dma_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                      // emits s_waitcnt vmcnt(0) for the pending LDS-DMA, then s_barrier
+        if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
+        const char* sa = smem + (kt & 1) * 2 * TILE2_BYTES;
+        const char* sw = sa + TILE2_BYTES;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            typename Frag8<T>::type fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag(sa, wm * 128 + i * 32 + fr, kc);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = load_frag(sw, wn * 64 + j * 32 + fr, kc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+    if constexpr (SZ == 2) {
+        if (p.vec == 1 && p.act != AFHIP_ACT_SWIGLU && !p.out_f32) {
+            // ---- epilogue through LDS: every wave owns a [128 rows x 64 cols] bf16 image (16 KiB, 128-B rows,
+            //      16-B chunks XOR-swizzled by row & 7); registers -> LDS as 8-B packs, LDS -> global as whole
+            //      128-B row segments (16 B per lane), residual read the same way.
+            __syncthreads();                                  // every wave has finished reading the K tiles
+            char* img = smem + wave * 16384;
+            const T* bias = reinterpret_cast<const T*>(p.bias);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = j * 32 + 8 * g + 4 * fh;   // column inside the wave's 64
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+                        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n0 + wn * 64 + nl);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) bv[k] = (float)b4[k];
                     }
-                    if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)m * p.ldc + n] = v;
-                    else C[(long long)m * p.ldc + n] = from_f32<T>(v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 32 + fr;
+                        bf16x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float v = acc[i][j][4 * g + k] + bv[k];
+                            if (p.act == AFHIP_ACT_GELU) v = gelu_act<T>(v);
+                            o[k] = (bf16)v;
+                        }
+                        *reinterpret_cast<bf16x4*>(img + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl >> 2) & 1) * 8) = o;
+                    }
                 }
+            __syncthreads();
+            const T* res = reinterpret_cast<const T*>(p.res);
+            T* C = reinterpret_cast<T*>(p.C);
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx >> 3, ch = idx & 7;
+                const int m = m0 + wm * 128 + row;
+                if (m >= p.M) continue;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 128 + ((ch ^ (row & 7)) << 4));
+                const long long col = n0 + wn * 64 + ch * 8;
+                if (res) {
+                    const long long rrow = (long long)(p.res_row_mod > 0 ? (m % p.res_row_mod) : m) * p.ldres;
+                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + rrow + col);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)r[k]);
+                }
+                *reinterpret_cast<bf16x8*>(C + (long long)m * p.ldc + col) = v;
             }
+            return;
+        }
     }
+    epilogue<T, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 }  // namespace
@@ -217,6 +445,12 @@ struct GemmProf {
     int* dtype = nullptr;
 } g_prof;
 }  // namespace
+
+static bool force_small_tile() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AFHIP_GEMM_SMALL_TILE"); v = (e && e[0] == '1') ? 1 : 0; }   // A/B switch for benchmarking
+    return v == 1;
+}
 
 extern "C" int afhip_prof_enable(int max_launches) {
     AFHIP_CHECK(max_launches > 0, "afhip_prof_enable: bad capacity");
@@ -288,19 +522,43 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldres = a->ldres;
     p.act = a->act; p.res_row_mod = a->res_row_mod;
     p.conv_Tin = a->conv_Tin; p.conv_Tout = a->conv_Tout; p.conv_stride = a->conv_stride; p.conv_C = a->conv_C;
-    p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     p.out_f32 = a->out_f32;
+    {
+        const size_t osz = a->out_f32 ? 4 : sz;
+        const bool al = ((uintptr_t)a->C % (4 * osz)) == 0 && (a->ldc % 4) == 0 &&
+                        (!a->bias || ((uintptr_t)a->bias % (4 * sz)) == 0) &&
+                        (!a->residual || (((uintptr_t)a->residual % (4 * sz)) == 0 && (a->ldres % 4) == 0));
+        const bool al8 = ((uintptr_t)a->C % 16) == 0 && (a->ldc % 8) == 0 &&
+                         (!a->residual || (((uintptr_t)a->residual % 16) == 0 && (a->ldres % 8) == 0));
+        p.vec = (al && (a->N % 4) == 0 && (a->act != AFHIP_ACT_SWIGLU || (a->N % 8) == 0)) ? 1 : 0;
+        if (a->dtype == AFHIP_BF16 && !al8) p.vec = p.vec ? 2 : 0;    // 2 = 4-wide only (no 16-byte rows): skip LDS path
+    }
+    // large, tile-aligned problems take the 256x256 LDS-DMA kernel; everything else the 128x128 register-staged one
+    const bool big = (a->N % BN2 == 0) && a->M >= 1024 && !force_small_tile();
+    if (big) { p.tiles_m = cdiv(a->M, BM2); p.tiles_n = cdiv(a->N, BN2); }
+    else { p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN); }
     const long long nwg = (long long)p.tiles_m * p.tiles_n;
     AFHIP_CHECK(nwg < (1ll << 31), "afhip_gemm: grid too large");
-    const size_t lds = 4 * TILE_BYTES;
+    const size_t lds = big ? 4 * (size_t)TILE2_BYTES : 4 * (size_t)TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
+    if (big) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+    }
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     const int slot = g_prof.n;
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
-    if (a->dtype == AFHIP_BF16)
-        hipLaunchKernelGGL(gemm_kernel<bf16>, dim3((unsigned)nwg), dim3(256), lds, s, p);
-    else
-        hipLaunchKernelGGL(gemm_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, s, p);
+    if (big) {
+        if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(gemm256_kernel<bf16>, dim3((unsigned)nwg), dim3(512), lds, s, p);
+        else hipLaunchKernelGGL(gemm256_kernel<float>, dim3((unsigned)nwg), dim3(512), lds, s, p);
+    } else {
+        if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(gemm_kernel<bf16>, dim3((unsigned)nwg), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(gemm_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, s, p);
+    }
     if (rec) {
         (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
         g_prof.flops[slot] = 2.0 * (double)a->M * (double)a->N * (double)a->K;

@@ -281,3 +281,40 @@ def test_masked_argmax_first_index_ties():
     mask = torch.ones(V, dtype=torch.bool); mask[2:4] = False; mask[256:4800] = False
     ref = x.masked_fill(mask[None], float("-inf")).argmax(-1)
     assert tok.cpu().tolist() == ref.tolist() == [700, 2, 4500]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_big_tile_path(dt):
+    """Shapes that dispatch to the 256x256 LDS-DMA kernel (N % 256 == 0, M >= 1024): M edge, epilogues, conv, swiglu."""
+    from audio_intelligence_amd import ops, _lib as L
+    tol = _tol(dt, (3e-5, 3e-5), (2e-2, 2e-2))
+    M, N, K = 1500, 512, 1280
+    ad, af = _q(_rand(M, K, seed=41), dt)
+    wd, wf = _q(_rand(N, K, seed=42, scale=0.03), dt)
+    bd, bf = _q(_rand(N, seed=43, scale=0.1), dt)
+    rd, rf = _q(_rand(M, N, seed=44), dt)
+    _check(ops.gemm(ad, wd, bias=bd, act=L.ACT_GELU, residual=rd), F.gelu(af @ wf.T + bf) + rf, *tol, "big gemm epilogue")
+    # A = I block against asymmetric integers (exact)
+    eye = torch.zeros(1024, 256); eye[:256] = torch.eye(256)
+    wi = ((torch.arange(256)[:, None] * 5 + torch.arange(256)[None, :] * 3) % 61 - 30).float()
+    ed, _ = _q(eye, dt); wid, wif = _q(wi, dt)
+    c = ops.gemm(ed, wid).float().cpu()
+    assert torch.equal(c[:256], wif.T.contiguous()) and float(c[256:].abs().max()) == 0.0
+    # implicit conv, both strides, time axis long enough for M >= 1024
+    for stride in (1, 2):
+        B, Tin, Cin, Cout = 2, 1100 * stride, 128, 256
+        Tout = (Tin + 2 - 3) // stride + 1
+        xd, xf = _q(_rand(B, Tin, Cin, seed=45), dt)
+        wq = _rand(Cout, Cin, 3, seed=46, scale=0.05).to(dt)
+        cb, cbf = _q(_rand(Cout, seed=47, scale=0.1), dt)
+        pos, posf = _q(_rand(Tout, Cout, seed=48), dt)
+        wp = wq.permute(0, 2, 1).reshape(Cout, 3 * Cin).contiguous().to(_dev())
+        y = ops.gemm(xd, wp, bias=cb, act=L.ACT_GELU, conv=(Tout, stride), residual=pos, res_row_mod=Tout)
+        ref = F.gelu(F.conv1d(xf.permute(0, 2, 1), wq.float(), cbf, stride=stride, padding=1)).permute(0, 2, 1) + posf[None]
+        _check(y, ref.reshape(B * Tout, Cout), *tol, f"big conv stride {stride}")
+    # swiglu
+    Mh, H, I = 1100, 256, 256
+    xd, xf = _q(_rand(Mh, H, seed=49), dt)
+    g = _rand(I, H, seed=50, scale=0.1).to(dt); u = _rand(I, H, seed=51, scale=0.1).to(dt)
+    packed = torch.stack([g.view(I // 32, 32, H), u.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous().to(_dev())
+    _check(ops.gemm(xd, packed, act=L.ACT_SWIGLU), F.silu(xf @ g.float().T) * (xf @ u.float().T), *tol, "big swiglu")
