@@ -1,0 +1,156 @@
+"""Host-side logic of the drop-in classes on CPU (no GPU): vocabulary / batch dict / masks / state-dict keys against
+the reference golden, length maths, KV-cache bookkeeping, long-audio windowing -- and the product path's refusal to
+run without the HIP device (no CPU fallback)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures_common as fc
+from tests import helpers as H
+
+
+class _FakeContinuous:
+    """stand-in with the AbsIO surface ContinuousAudioIO shows to UALMPreprocessor (no kernels involved)"""
+    modality, is_discrete = "audio", False
+
+    def __init__(self, io):
+        self.io = io
+
+    def preprocess(self, data):
+        wav, sr = data
+        n = min(wav.shape[-1], 480000)
+        after = self.io._after_length(n)
+        pads = np.zeros((after, 1), np.int32)
+        return pads, (after, np.zeros((3000, 128), np.float32)), pads
+
+    def find_length(self, data):
+        return self.io.find_length(data)
+
+
+def _cpu_io():
+    from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+    io = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="float32", device="cpu", _skip_loading=True)
+    io.sample_rate, io.hop_length, io.n_samples, io.d_model = 16000, 160, 480000, 384
+    return io
+
+
+def test_length_table_and_find_length():
+    g, _ = H.golden()
+    io = _cpu_io()
+    for row in g["length_table"]:
+        assert io.find_length((np.zeros(row["n"], np.float32), 16000)) == row["find_length"]
+        assert io._after_length(min(row["n"], 480000)) == row["after_length"]
+    assert io.find_length((np.zeros(80000, np.float32), 8000)) == g["find_length_8k"]
+    assert io.feature_dim() == 384 and io.model is None
+
+
+def test_mel_filter_bank_matches_reference():
+    from audio_intelligence_amd.multimodal_io.feature_extraction import mel_filter_bank
+    g, _ = H.golden()
+    f = mel_filter_bank()
+    assert list(f.shape) == g["filters"]["shape"] and int((f != 0).sum()) == g["filters"]["nnz"]
+    np.testing.assert_allclose(f.reshape(-1)[g["filters"]["sample_idx"]], g["filters"]["sample_val"], rtol=1e-12, atol=1e-15)
+
+
+def test_vocabulary_and_collate_against_reference_golden():
+    from audio_intelligence_amd import ualm_job
+    g, _ = H.golden()
+    lcfg = H.tiny_llm()[0]
+    text, audio = H.stub_ios(lcfg["text_vocab"])
+    ios = {"text": text, "discrete_audio": audio, "continuous_audio": _FakeContinuous(_cpu_io())}
+    vocab, iv = ualm_job.build_vocabulary(ios)
+    assert len(vocab) == g["llm_tiny"]["vocab_size"]
+    assert {k: [list(x) for x in v] for k, v in iv.items()} == g["llm_tiny"]["intervals"]
+    pre = ualm_job.UALMPreprocessor(False, ios, vocab, iv)
+    data = {"audio": (fc.make_wav(1000, 160000)[None], 16000), "text": [["user", "text", [0, 5, 6, 7]]]}
+    b = pre.collate_fn([(("audio_to_caption", "x", "y"), data)])
+    c = g["collate_small"]
+    assert list(b["seqs"].shape) == c["seqs_shape"] and b["seqs"][0, :, 0].tolist() == c["seqs_stream0"]
+    assert b["continuous_audio_indices"].tolist() == c["indices"] and b["continuous_audio_lengths"].tolist() == c["lengths"]
+    assert list(b["continuous_audio_feats"].shape) == c["feats_shape"]
+    assert pre.find_length(("audio_to_caption", "x", "y"), data) == c["find_length"]
+    # ragged batch: right padding with pad id 0, per-sample feature indices (ualm_job.py:262-307)
+    d2 = {"audio": (fc.make_wav(1, 80000)[None], 16000), "text": [["user", "text", [9, 9]]]}
+    b2 = pre.collate_fn([(("audio_to_caption", "x", "y"), data), (("audio_to_caption", "x", "y"), d2)])
+    assert list(b2["seqs"].shape) == [2, 261, 8] and int(b2["seqs"][1, 134:].abs().sum()) == 0
+    assert b2["continuous_audio_indices"].tolist() == [[0, 10, 250], [1, 8, 125]]
+    # a bad sample is dropped, not fatal (ualm_job.py:236-250); an all-bad batch raises
+    b3 = pre.collate_fn([(("audio_to_caption", "x", "y"), data), (("no_such_task", "x", "y"), data)])
+    assert b3["seqs"].shape[0] == 1
+    with pytest.raises(ValueError):
+        pre.collate_fn([(("no_such_task", "x", "y"), data)])
+
+
+def test_parallel_llm_structure_masks_and_intervals_on_cpu():
+    import json, os, tempfile
+    from audio_intelligence_amd.lm.parallel import ParallelHFModel, KVCache
+    g, _ = H.golden()
+    lcfg, lsd, vocab, iv = H.tiny_llm()
+    ecfg, esd = H.tiny_enc()
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+    text, audio = H.stub_ios(lcfg["text_vocab"])
+    cont = _cpu_io()
+    cont.model = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(ecfg))
+    with tempfile.TemporaryDirectory() as d:
+        json.dump({"architectures": ["Qwen2ForCausalLM"], "hidden_size": 768, "num_hidden_layers": 12, "num_attention_heads": 12,
+                   "num_key_value_heads": 2, "intermediate_size": 3072, "rope_theta": 1e6, "rms_norm_eps": 1e-6}, open(os.path.join(d, "config.json"), "w"))
+        model = ParallelHFModel(d, multimodal_io={"text": text, "discrete_audio": audio, "continuous_audio": cont}, vocab=vocab, vocab_intervals=iv)
+    full = dict(lsd)
+    full.update({"multimodal_io_dict.continuous_audio.model." + k: v for k, v in esd.items()})
+    r = model.load_state_dict(full, strict=True)              # reference checkpoint key set, strict (scripts/inference.py:150-152)
+    assert not r.missing_keys and not r.unexpected_keys
+    keys = sorted(model.state_dict().keys())
+    assert len(keys) == g["llm_tiny"]["n_state_dict_keys"]
+    assert hashlib.sha256("\n".join(keys).encode()).hexdigest() == g["llm_tiny"]["state_dict_keys_sha256"]
+    model.prepare_inference()
+    L = g["llm_tiny"]
+    assert model.modality_mask[0, 0].sum(-1).tolist() == L["modality_mask_rowsum"]
+    assert model.text_mask[0, 0].sum(-1).tolist() == L["text_mask_rowsum"]
+    assert model.audio_mask[0, 0].sum(-1).tolist() == L["audio_mask_rowsum"]
+    ivt, pad_only = model._allowed_intervals("text")
+    assert ivt.tolist() == [[2, 4], [256, 256 + 16384]] and pad_only
+    ivm, _ = model._allowed_intervals("modality")
+    assert ivm.tolist() == [[7, 9], [10, 13]]
+    _, pad_only_audio = model._allowed_intervals("audio")
+    assert not pad_only_audio
+    assert model.num_stream == 8 and model.eos_token_id == 2 and model.eot_token_id == 3
+    # no CPU fallback: compute on a CPU-resident model must raise, not silently run
+    from audio_intelligence_amd._lib import AfhipError
+    with pytest.raises(AfhipError):
+        model._step(input_ids=torch.zeros(1, 1, 8, dtype=torch.long))
+    c = KVCache(2, 1, 2, 64, 64, torch.float32, "cpu")
+    c.k[:, :, :, :10] = 1.0
+    c.length = 10
+    c.reserve(100)
+    assert c.cap == 128 and float(c.k[:, :, :, :10].min()) == 1.0 and float(c.k[:, :, :, 10:].abs().max()) == 0.0
+    c.batch_select_indices(torch.zeros(3, dtype=torch.long))
+    assert c.batch == 3 and c.get_seq_length() == 10
+
+
+def test_product_path_refuses_cpu():
+    from audio_intelligence_amd import ops
+    from audio_intelligence_amd._lib import AfhipError
+    from audio_intelligence_amd.multimodal_io.feature_extraction import WhisperFeatureExtractorHIP
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(AfhipError):
+        ops.gemm(torch.zeros(128, 64), torch.zeros(128, 64))
+    with pytest.raises(AfhipError):
+        WhisperFeatureExtractorHIP()(np.zeros(16000, np.float32), sampling_rate=16000)
+
+
+def test_long_audio_windowing():
+    from audio_intelligence_amd.long_audio import split_windows, shard_range
+    assert split_windows(0) == []
+    assert split_windows(480000) == [(0, 480000)]
+    w = split_windows(9600000)                       # 10 minutes
+    assert len(w) == 20 and w[-1] == (9120000, 9600000)
+    assert split_windows(500000) == [(0, 480000), (480000, 500000)]
+    for n, world in ((80, 8), (20, 8), (3, 8), (7, 2)):
+        spans = [shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+        sizes = [h - l for l, h in spans]
+        assert max(sizes) - min(sizes) <= 1
