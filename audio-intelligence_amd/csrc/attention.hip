@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int qrow = q0 + wave * 32 + fr;                 // this lane's query
     const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
     const int qpos = p.q_pos0 + qrow;
+    const int wave_qpos_min = p.q_pos0 + q0 + wave * 32;   // smallest query position held by this wave
 
     const char* qb = p.q + ((long long)b * p.q_bs + (long long)hq * p.q_hs) * SZ;
     const char* kb = p.k + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
@@ -150,37 +151,47 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
 
-        // ---- mask + online softmax (query = this lane's column) ----
+        // ---- online softmax (query = this lane's column).  Masking is compiled into boundary tiles only (wave-uniform
+        //      branch): interior tiles run max / fma / exp2 / add per score and nothing else. ----
+        const bool edge = (k0 + KT > klen) || (p.causal && (k0 + KT - 1 > wave_qpos_min));
+        if (edge) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + ks * 32 + swap23(mfma32_row(e, lane));
+                    const bool ok = key < klen && (!p.causal || key <= qpos);
+                    st[ks][e] = ok ? st[ks][e] : -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = k0 + ks * 32 + swap23(mfma32_row(e, lane));
-                const bool ok = key < klen && (!p.causal || key <= qpos);
-                const float s = ok ? st[ks][e] * p.scale_log2 : -INFINITY;
-                st[ks][e] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[ks][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_i, mx);
+        const float m_new = fmaxf(m_i, mx);                 // raw (unscaled) score units
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_i - m_use);            // m_i = -inf -> 0
+        if (__any(m_new != m_i)) {                           // the running max moved for some query of this wave
+            const float alpha = __builtin_amdgcn_exp2f((m_i - m_use) * p.scale_log2);   // m_i = -inf -> 0
+            l_i *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+            m_i = m_new;
+        }
+        const float moff = -m_use * p.scale_log2;
         float psum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(st[ks][e] - m_use);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[ks][e], p.scale_log2, moff));
                 st[ks][e] = pv;
                 psum += pv;
             }
-        l_i = l_i * alpha + psum;
-        m_i = m_new;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+        l_i += psum;
 
         // ---- O^T += V^T . P^T ; step s covers keys [16s, 16s+16) of the tile ----
 #pragma unroll
