@@ -29,7 +29,13 @@ struct AttnP {
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
-__device__ __forceinline__ int vswz(int row) { return ((row >> 3) ^ row) & 7; }
+// chunk swizzles that make the 32-row ds_read_b128 operand pattern bank-conflict free (see gemm.hip swz): 128-B rows
+// pair up in a 256-B bank row -> (row >> 1) & 7; 256-B rows own a bank row -> row & 15
+template <int ROWBYTES> __device__ __forceinline__ int rswz(int row) {
+    if constexpr (ROWBYTES == 128) return (row >> 1) & 7;
+    else if constexpr (ROWBYTES == 256) return row & 15;
+    else return row & 7;
+}
 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
@@ -101,13 +107,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         for (int i = 0; i < NLD; ++i) {
             const int c = tid + 256 * i;
             const int row = c / KCPR, cc = c % KCPR;
-            st16(Ks + row * KROWB + ((cc ^ (row & 7)) << 4), rk[i]);
+            st16(Ks + row * KROWB + ((cc ^ rswz<KROWB>(row)) << 4), rk[i]);
             // transpose V chunk: element e of this chunk is V[key=row][d = cc*EPC + e] -> Vt[d][key]
             const int kch = row / EPC, kin = row % EPC;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const int d = cc * EPC + e;
-                char* dst = Vt + d * VROWB + ((kch ^ vswz(d)) << 4) + kin * SZ;
+                char* dst = Vt + d * VROWB + ((kch ^ rswz<VROWB>(d)) << 4) + kin * SZ;
                 if constexpr (SZ == 2) {
                     const uint32_t wv = rv[i][e >> 1];
                     *reinterpret_cast<uint16_t*>(dst) = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
@@ -140,11 +146,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 typename Frag8<T>::type kf;
                 if constexpr (SZ == 2) {
                     const int ch = dc * 2 + fh;
-                    kf = *reinterpret_cast<const bf16x8*>(Ks + krow * KROWB + ((ch ^ (krow & 7)) << 4));
+                    kf = *reinterpret_cast<const bf16x8*>(Ks + krow * KROWB + ((ch ^ rswz<KROWB>(krow)) << 4));
                 } else {
                     const int ch = dc * 4 + fh * 2;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + ((ch ^ (krow & 7)) << 4));
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + (((ch + 1) ^ (krow & 7)) << 4));
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + ((ch ^ rswz<KROWB>(krow)) << 4));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + (((ch + 1) ^ rswz<KROWB>(krow)) << 4));
                     kf = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 }
                 st[ks] = mma16(kf, qf[dc], st[ks]);
@@ -205,11 +211,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 typename Frag8<T>::type vf;
                 if constexpr (SZ == 2) {
                     const int ch = s * 2 + fh;
-                    vf = *reinterpret_cast<const bf16x8*>(Vt + vrow * VROWB + ((ch ^ vswz(vrow)) << 4));
+                    vf = *reinterpret_cast<const bf16x8*>(Vt + vrow * VROWB + ((ch ^ rswz<VROWB>(vrow)) << 4));
                 } else {
                     const int ch = s * 4 + fh * 2;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + ((ch ^ vswz(vrow)) << 4));
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + (((ch + 1) ^ vswz(vrow)) << 4));
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + ((ch ^ rswz<VROWB>(vrow)) << 4));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + (((ch + 1) ^ rswz<VROWB>(vrow)) << 4));
                     vf = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 }
                 ot[dt] = mma16(vf, pf, ot[dt]);

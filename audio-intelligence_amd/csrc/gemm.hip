@@ -1,7 +1,7 @@
 // MFMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] . W[N,K]^T), both operands K-contiguous ("NT").
 // One kernel template serves bf16 (v_mfma_f32_32x32x16_bf16) and exact f32 (v_mfma_f32_32x32x2_f32) because
 // the LDS image is defined in BYTES: a tile is 128 rows x 128 B (64 bf16 or 32 f32 of K), 16-B chunks
-// XOR-swizzled by (row & 7), and every lane reads 8 consecutive K elements of its row (common.h mma16).
+// XOR-swizzled by swz(row), and every lane reads 8 consecutive K elements of its row (common.h mma16).
 // 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA tiles, f32 accumulators.
 // Register-prefetched double-buffered LDS, one barrier per K tile.  Optional implicit im2col on A (conv1d
 // k=3 pad=1, channel-last input) and fused epilogues: bias, erf-GELU, SwiGLU pair, residual / position table.
@@ -11,6 +11,11 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // tile rows, bytes of K per row
+// XOR swizzle of the 16-B chunk index inside a 128-B LDS row.  Two tile rows share one 256-B bank row, and a
+// ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: with (row >> 1) & 7 the 8 even and
+// the 8 odd rows of every group land on 8 distinct chunks each -> all 64 banks, conflict-free (row & 7 was 2-way:
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 constexpr int TILE_BYTES = BM * ROWB;           // 16 KiB per operand per stage
 
 struct GemmP {
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 32 * i;
-            const int off = row * ROWB + ((cc ^ (row & 7)) << 4);
+            const int off = row * ROWB + ((cc ^ swz(row)) << 4);
             st16(sa + off, ra[i]);
             st16(sw + off, rw[i]);
         }
@@ -220,14 +225,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 const int roww = wn * 64 + i * 32 + fr;
                 if constexpr (SZ == 2) {
                     const int ch = kc * 2 + fh;
-                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + rowa * ROWB + ((ch ^ (rowa & 7)) << 4));
-                    fb[i] = *reinterpret_cast<const bf16x8*>(sw + roww * ROWB + ((ch ^ (roww & 7)) << 4));
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + rowa * ROWB + ((ch ^ swz(rowa)) << 4));
+                    fb[i] = *reinterpret_cast<const bf16x8*>(sw + roww * ROWB + ((ch ^ swz(roww)) << 4));
                 } else {
                     const int ch = kc * 4 + fh * 2;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + rowa * ROWB + ((ch ^ (rowa & 7)) << 4));
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + rowa * ROWB + (((ch + 1) ^ (rowa & 7)) << 4));
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sw + roww * ROWB + ((ch ^ (roww & 7)) << 4));
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(sw + roww * ROWB + (((ch + 1) ^ (roww & 7)) << 4));
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + rowa * ROWB + ((ch ^ swz(rowa)) << 4));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + rowa * ROWB + (((ch + 1) ^ swz(rowa)) << 4));
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sw + roww * ROWB + ((ch ^ swz(roww)) << 4));
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(sw + roww * ROWB + (((ch + 1) ^ swz(roww)) << 4));
                     fa[i] = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     fb[i] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 }
@@ -262,9 +267,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 //     top of iteration kt: vmcnt(0) + barrier   -> tile kt has landed for every wave, stage (kt+1)&1 is free
 //                          issue DMA of tile kt+1 into stage (kt+1)&1   (in flight during the MFMAs below)
 //                          MFMAs on stage kt&1
-// The LDS image is the same byte layout as above (128-B rows, 16-B chunk c of row r stored at slot c ^ (r & 7)).
+// The LDS image is the same byte layout as above (128-B rows, 16-B chunk c of row r stored at slot c ^ swz(r)).
 // An LDS-DMA wave-instruction writes 64 x 16 B linearly (= 8 whole rows), so the swizzle is applied on the SOURCE:
-// the lane that fills slot s of row r fetches chunk s ^ (r & 7).  Out-of-range conv taps read a zero page.
+// the lane that fills slot s of row r fetches chunk s ^ swz(r).  Out-of-range conv taps read a zero page.
 __device__ __attribute__((aligned(16))) char g_zero_page[256];
 
 constexpr int BM2 = 256, BN2 = 256;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 
     // ---- DMA coordinates: pass i of wave w fills rows (i*8 + w)*8 .. +8 of a tile; lane -> (row, slot) ----
     const int lrow = lane >> 3, lslot = lane & 7;
-    const int src_chunk = lslot ^ lrow;             // (row & 7) == lrow because pass bases are multiples of 8 rows
+    const int src_chunk = lslot ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7);   // = lslot ^ swz(row): pass bases are multiples of 8 rows
     const char* a_ptr[4];
     int a_ts[4];
     const char* w_ptr[4];
@@ -309,31 +314,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     }
     const int nk = p.K / BK;
 
-    auto dma_tile = [&](int kt, int buf) {
+    // one quarter (pass i: 8 rows of A + 8 rows of W per wave) of the LDS-DMA traffic of K tile kt; the four quarters
+    // are issued between the four MFMA groups of the previous tile so the matrix pipe never waits behind a burst of
+    // DMA issues (an LDS-DMA costs ~60-180 issue cycles next to MFMAs)
+    auto dma_quarter = [&](int kt, int buf, int i) {
         char* sa = smem + buf * 2 * TILE2_BYTES;
         char* sw = sa + TILE2_BYTES;
         const long long kbyte = (long long)kt * ROWB;
-        int tap = 0, c0 = 0;
+        const int lds_off = (i * 8 + wave) * 1024;      // wave-uniform; the hardware adds lane * 16
+        const char* ga;
         if (p.conv_C > 0) {
             const int k0 = kt * BK;
-            tap = k0 / p.conv_C;
-            c0 = k0 - tap * p.conv_C;
+            const int tap = k0 / p.conv_C, c0 = k0 - tap * p.conv_C;
+            const int ts = a_ts[i] + tap;
+            ga = (ts >= 0 && ts < p.conv_Tin) ? a_ptr[i] + ((long long)ts * p.conv_C + c0) * SZ : g_zero_page + lslot * 16;
+        } else {
+            ga = a_ptr[i] + kbyte;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int lds_off = (i * 8 + wave) * 1024;      // wave-uniform; the hardware adds lane * 16
-            const char* ga;
-            if (p.conv_C > 0) {
-                const int ts = a_ts[i] + tap;
-                ga = (ts >= 0 && ts < p.conv_Tin) ? a_ptr[i] + ((long long)ts * p.conv_C + c0) * SZ : g_zero_page + lslot * 16;
-            } else {
-                ga = a_ptr[i] + kbyte;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
-                                             (__attribute__((address_space(3))) void*)(sa + lds_off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kbyte),
-                                             (__attribute__((address_space(3))) void*)(sw + lds_off), 16, 0, 0);
-        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                         (__attribute__((address_space(3))) void*)(sa + lds_off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kbyte),
+                                         (__attribute__((address_space(3))) void*)(sw + lds_off), 16, 0, 0);
     };
 
     f32x16 acc[4][2];
@@ -348,21 +349,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     auto load_frag = [&](const char* base, int row, int kc) -> typename Frag8<T>::type {
         if constexpr (SZ == 2) {
             const int ch = kc * 2 + fh;
-            return *reinterpret_cast<const bf16x8*>(base + row * ROWB + ((ch ^ (row & 7)) << 4));
+            return *reinterpret_cast<const bf16x8*>(base + row * ROWB + ((ch ^ swz(row)) << 4));
         } else {
             const int ch = kc * 4 + fh * 2;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(base + row * ROWB + ((ch ^ (row & 7)) << 4));
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(base + row * ROWB + (((ch + 1) ^ (row & 7)) << 4));
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(base + row * ROWB + ((ch ^ swz(row)) << 4));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(base + row * ROWB + (((ch + 1) ^ swz(row)) << 4));
             return f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         }
     };
 
-    dma_tile(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_quarter(0, 0, i);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                      // emits s_waitcnt vmcnt(0) for the pending LDS-DMA, then s_barrier
-        if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
+        const bool more = kt + 1 < nk;
         const char* sa = smem + (kt & 1) * 2 * TILE2_BYTES;
         const char* sw = sa + TILE2_BYTES;
+        // the next tile's LDS-DMA is issued in the first half of this tile's MFMA groups, two quarters per group: late
+        // enough not to delay the first MFMAs behind a burst of DMA issues, early enough to land before the barrier
+        constexpr int DMA_GROUPS = KC >= 2 ? 2 : 1;
+        constexpr int QPG = 4 / DMA_GROUPS;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             typename Frag8<T>::type fa[4], fb[2];
@@ -370,6 +376,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             for (int i = 0; i < 4; ++i) fa[i] = load_frag(sa, wm * 128 + i * 32 + fr, kc);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = load_frag(sw, wn * 64 + j * 32 + fr, kc);
+            if (more && kc < DMA_GROUPS) {
+#pragma unroll
+                for (int qq = 0; qq < QPG; ++qq) dma_quarter(kt + 1, (kt + 1) & 1, kc * QPG + qq);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     if constexpr (SZ == 2) {
         if (p.vec == 1 && p.act != AFHIP_ACT_SWIGLU && !p.out_f32) {
             // ---- epilogue through LDS: every wave owns a [128 rows x 64 cols] bf16 image (16 KiB, 128-B rows,
-            //      16-B chunks XOR-swizzled by row & 7); registers -> LDS as 8-B packs, LDS -> global as whole
+            //      16-B chunks XOR-swizzled by swz(row)); registers -> LDS as 8-B packs, LDS -> global as whole
             //      128-B row segments (16 B per lane), residual read the same way.
             __syncthreads();                                  // every wave has finished reading the K tiles
             char* img = smem + wave * 16384;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                             if (p.act == AFHIP_ACT_GELU) v = gelu_act<T>(v);
                             o[k] = (bf16)v;
                         }
-                        *reinterpret_cast<bf16x4*>(img + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl >> 2) & 1) * 8) = o;
+                        *reinterpret_cast<bf16x4*>(img + row * 128 + ((((nl >> 3)) ^ swz(row)) << 4) + ((nl >> 2) & 1) * 8) = o;
                     }
                 }
             __syncthreads();
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                 const int row = idx >> 3, ch = idx & 7;
                 const int m = m0 + wm * 128 + row;
                 if (m >= p.M) continue;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 128 + ((ch ^ (row & 7)) << 4));
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 128 + ((ch ^ swz(row)) << 4));
                 const long long col = n0 + wn * 64 + ch * 8;
                 if (res) {
                     const long long rrow = (long long)(p.res_row_mod > 0 ? (m % p.res_row_mod) : m) * p.ldres;
