@@ -34,7 +34,8 @@ class AttnArgs(C.Structure):
                 ("ld_q", C.c_int), ("ld_kv", C.c_int), ("ld_o", C.c_int),
                 ("q_batch_stride", C.c_longlong), ("kv_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
                 ("q_head_stride", C.c_longlong), ("kv_head_stride", C.c_longlong),
-                ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int)]
+                ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
+                ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t)]
 
 
 class EncoderWeights(C.Structure):
@@ -89,7 +90,7 @@ SIGNATURES = {
     "afhip_attention": (_I, [C.POINTER(AttnArgs), _P]),
     "afhip_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderWeights), _I]),
     "afhip_encoder_forward": (_I, [C.POINTER(EncoderWeights), _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
-    "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I]),
+    "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I, _I]),
     "afhip_llm_forward": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
     "afhip_lm_head": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _P, _P, _Z, _P]),
     "afhip_masked_argmax": (_I, [_P, _I, _I, _P, _I, _P, _P]),

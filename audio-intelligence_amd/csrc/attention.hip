@@ -23,9 +23,12 @@ struct AttnP {
     int B, Tq, Tk, n_q, n_kv, hd;
     long long ld_q, ld_kv, ld_o;
     long long q_bs, kv_bs, o_bs;
-    long long q_hs, kv_hs;
+    long long q_hs, kv_hs, o_hs;
     int causal, q_pos0;
     float scale_log2;
+    int key_split;          // > 0: blockIdx.x enumerates key ranges of this many keys (Tq <= 32), partials go to part_o / part_ml
+    float* part_o;          // [split][B][n_q][32][HD] unnormalised O^T columns
+    float* part_ml;         // [split][B][n_q][32][2]  running max (raw score units) and sum
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int fr = lane & 31, fh = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y;
     const int hkv = hq / (p.n_q / p.n_kv);
-    const int q0 = blockIdx.x * QT;
+    const int split = p.key_split > 0 ? blockIdx.x : 0;
+    const int q0 = p.key_split > 0 ? 0 : blockIdx.x * QT;
     const int qrow = q0 + wave * 32 + fr;                 // this lane's query
     const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
     const int qpos = p.q_pos0 + qrow;
@@ -71,7 +75,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         const int last = p.q_pos0 + (q0 + QT - 1 < p.Tq - 1 ? q0 + QT - 1 : p.Tq - 1) + 1;
         kend = last < kend ? last : kend;
     }
-    const int ntiles = (kend + KT - 1) / KT;
+    int kbeg = 0;
+    if (p.key_split > 0) {
+        kbeg = split * p.key_split;
+        const int ke = kbeg + p.key_split;
+        kend = ke < kend ? ke : kend;
+        if (kbeg > kend) kbeg = kend;
+    }
+    const int tbeg = kbeg / KT;
+    const int ntiles = (kend + KT - 1) / KT;      // tiles [tbeg, ntiles)
 
     // ---- Q fragments (B operand), resident for the whole kernel ----
     typename Frag8<T>::type qf[DSTEPS];
@@ -124,13 +136,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         }
     };
 
-    if (ntiles > 0) {
-        load_tile(0);
+    if (ntiles > tbeg) {
+        load_tile(tbeg);
         store_tile();
     }
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tbeg; t < ntiles; ++t) {
         const int k0 = t * KT;
         if (t + 1 < ntiles) load_tile(t + 1);
 
@@ -227,11 +239,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         __syncthreads();
     }
 
-    // ---- normalise and write O[query, d] ----
+    // ---- normalise and write O[query, d] (or the unnormalised partial of this key range) ----
     const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+    if (p.key_split > 0) {
+        if (wave == 0 && qrow < p.Tq) {
+            const long long slot = (((long long)split * p.B + b) * p.n_q + hq) * 32 + fr;
+            float* po = p.part_o + slot * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * fh;
+                    *reinterpret_cast<f32x4*>(po + d) = f32x4{ot[dt][4 * g], ot[dt][4 * g + 1], ot[dt][4 * g + 2], ot[dt][4 * g + 3]};
+                }
+            if (fh == 0) { p.part_ml[slot * 2] = m_i; p.part_ml[slot * 2 + 1] = l_tot; }
+        }
+        return;
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < p.Tq) {
-        T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * HD;
+        T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -252,6 +279,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
 }
 
+// merge the key-range partials of the split kernel: out = sum_s O_s * 2^((m_s - m) c) / sum_s l_s * 2^((m_s - m) c)
+template <typename T>
+__global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
+    const int row = blockIdx.x;                      // (b, hq, qrow) flattened
+    const int qrow = row % p.Tq, hq = (row / p.Tq) % p.n_q, b = row / (p.Tq * p.n_q);
+    const int d = threadIdx.x;
+    float m = -INFINITY;
+    for (int s = 0; s < n_split; ++s) {
+        const long long slot = (((long long)s * p.B + b) * p.n_q + hq) * 32 + qrow;
+        m = fmaxf(m, p.part_ml[slot * 2]);
+    }
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < n_split; ++s) {
+        const long long slot = (((long long)s * p.B + b) * p.n_q + hq) * 32 + qrow;
+        const float ms = p.part_ml[slot * 2];
+        const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
+        l += p.part_ml[slot * 2 + 1] * w;
+        o += p.part_o[slot * HD + d] * w;
+    }
+    T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
+    op[d] = from_f32<T>(l > 0.f ? o / l : 0.f);
+}
+
 }  // namespace
 
 extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
@@ -268,7 +318,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
                     (a->q_head_stride * sz) % 16 == 0 && (a->kv_head_stride * sz) % 16 == 0 &&
                     (a->q_batch_stride * sz) % 16 == 0 && (a->kv_batch_stride * sz) % 16 == 0 && (a->o_batch_stride * sz) % 16 == 0,
                 "afhip_attention: strides must keep 16-byte alignment");
-    AFHIP_CHECK(a->ld_o >= a->n_q * a->hd, "afhip_attention: ld_o too small");
+    AFHIP_CHECK(a->ld_o >= a->hd, "afhip_attention: ld_o too small");
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
     AFHIP_CHECK(a->n_q <= 65535 && a->B <= 65535, "afhip_attention: grid too large");
 
@@ -278,11 +328,25 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.B = a->B; p.Tq = a->Tq; p.Tk = a->Tk; p.n_q = a->n_q; p.n_kv = a->n_kv; p.hd = a->hd;
     p.ld_q = a->ld_q; p.ld_kv = a->ld_kv; p.ld_o = a->ld_o;
     p.q_bs = a->q_batch_stride; p.kv_bs = a->kv_batch_stride; p.o_bs = a->o_batch_stride;
-    p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride;
+    p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride; p.o_hs = a->o_head_stride > 0 ? a->o_head_stride : a->hd;
     p.causal = a->causal; p.q_pos0 = a->q_pos0;
     p.scale_log2 = a->scale * 1.4426950408889634f;
-    const dim3 grid(cdiv(a->Tq, QT), a->n_q, a->B), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // key-range splitting for tiny query counts (decode): partials + a combine pass
+    int n_split = 1;
+    p.key_split = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    if (a->key_split > 0) {
+        AFHIP_CHECK(a->key_split % KT == 0, "afhip_attention: key_split must be a multiple of %d", KT);
+        AFHIP_CHECK(a->Tq <= 32 && !a->causal, "afhip_attention: key_split needs Tq <= 32 and causal == 0");
+        n_split = cdiv(a->Tk, a->key_split);
+        const size_t need = (size_t)n_split * a->B * a->n_q * 32 * (a->hd + 2) * sizeof(float);
+        AFHIP_CHECK(a->partial_ws != nullptr && a->partial_ws_bytes >= need, "afhip_attention: partial workspace %zu < %zu bytes", (size_t)a->partial_ws_bytes, need);
+        AFHIP_CHECK(((uintptr_t)a->partial_ws % 16) == 0, "afhip_attention: partial workspace must be 16-byte aligned");
+        p.key_split = a->key_split;
+        p.part_o = (float*)a->partial_ws;
+        p.part_ml = p.part_o + (size_t)n_split * a->B * a->n_q * 32 * a->hd;
+    }
+    const dim3 grid(a->key_split > 0 ? n_split : cdiv(a->Tq, QT), a->n_q, a->B), block(256);
     const size_t lds = 2 * (size_t)KT * a->hd * sz;
     if (a->dtype == AFHIP_BF16) {
         if (a->hd == 64) hipLaunchKernelGGL((attn_kernel<bf16, 64>), grid, block, lds, s, p);
@@ -292,5 +356,11 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         else hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, lds, s, p);
     }
     AFHIP_LAUNCH_CHECK();
+    if (a->key_split > 0) {
+        const dim3 g2(a->B * a->n_q * a->Tq), b2(a->hd);
+        if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(attn_combine_kernel<bf16>, g2, b2, 0, s, p, n_split, a->hd);
+        else hipLaunchKernelGGL(attn_combine_kernel<float>, g2, b2, 0, s, p, n_split, a->hd);
+        AFHIP_LAUNCH_CHECK();
+    }
     return 0;
 }

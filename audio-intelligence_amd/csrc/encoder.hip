@@ -97,6 +97,7 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         a.ld_q = 3 * d; a.ld_kv = 3 * d; a.ld_o = d;
         a.q_batch_stride = (long long)Tp * 3 * d; a.kv_batch_stride = (long long)Tp * 3 * d; a.o_batch_stride = (long long)Tp * d;
         a.q_head_stride = hd; a.kv_head_stride = hd;
+        a.o_head_stride = 0; a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         a.causal = 0; a.q_pos0 = 0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
         if ((rc = afhip_attention(&a, s))) return rc;
         if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;

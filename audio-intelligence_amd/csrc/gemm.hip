@@ -7,6 +7,7 @@
 // k=3 pad=1, channel-last input) and fused epilogues: bias, erf-GELU, SwiGLU pair, residual / position table.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -275,7 +276,7 @@ __device__ __attribute__((aligned(16))) char g_zero_page[256];
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int TILE2_BYTES = BM2 * ROWB;   // 32 KiB per operand per stage
 
-template <typename T>
+template <typename T, bool CONV, int MF>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     constexpr int SZ = sizeof(T);
     constexpr int BK = ROWB / SZ;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         const int row = (i * 8 + wave) * 8 + lrow;
         int m = m0 + row;
         if (m > p.M - 1) m = p.M - 1;
-        if (p.conv_C > 0) {
+        if constexpr (CONV) {
             const int b = m / p.conv_Tout, t = m - b * p.conv_Tout;
             a_ts[i] = t * p.conv_stride - 1;
             a_ptr[i] = p.A + ((long long)b * p.conv_Tin) * p.conv_C * SZ + src_chunk * 16;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         const long long kbyte = (long long)kt * ROWB;
         const int lds_off = (i * 8 + wave) * 1024;      // wave-uniform; the hardware adds lane * 16
         const char* ga;
-        if (p.conv_C > 0) {
+        if constexpr (CONV) {
             const int k0 = kt * BK;
             const int tap = k0 / p.conv_C, c0 = k0 - tap * p.conv_C;
             const int ts = a_ts[i] + tap;
@@ -336,6 +337,101 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kbyte),
                                          (__attribute__((address_space(3))) void*)(sw + lds_off), 16, 0, 0);
     };
+
+    if constexpr (MF == 16) {
+        // ---- bf16 on v_mfma_f32_16x16x32_bf16: same LDS image, same DMA, 8 x 4 accumulator tiles of 16 x 16 per wave.
+        //      (The chip holds a higher clock on this MFMA shape than on 32x32x16 at equal cycles per FLOP.)
+        //      Lane (c = lane & 15, q = lane >> 4) reads 8 consecutive K elements [32 kk + 8 q, +8) of row c; with the
+        //      operands swapped (A = W, B = X) the lane ends up with output columns n = 16 j + 4 q + (0..3) of row m = 16 i + c.
+        static_assert(sizeof(T) == 2, "16x16x32 path is bf16 only");
+        f32x4 acc16[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c16 = lane & 15, q4 = lane >> 4;
+        auto k_tile16 = [&](int kt, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            __syncthreads();
+            const char* sa = smem + (kt & 1) * 2 * TILE2_BYTES;
+            const char* sw = sa + TILE2_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[8], fb[4];
+                const int ch = kk * 4 + q4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = wm * 128 + i * 16 + c16;
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((ch ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wn * 64 + j * 16 + c16;
+                    fb[j] = *reinterpret_cast<const bf16x8*>(sw + row * ROWB + ((ch ^ swz(row)) << 4));
+                }
+                if constexpr (MORE) {
+                    dma_quarter(kt + 1, (kt + 1) & 1, kk * 2);
+                    dma_quarter(kt + 1, (kt + 1) & 1, kk * 2 + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc16[i][j], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_quarter(0, 0, i);
+        for (int kt = 0; kt < nk - 1; ++kt) k_tile16(kt, std::true_type{});
+        k_tile16(nk - 1, std::false_type{});
+
+        // epilogue through LDS (host guarantees vec == 1, no SWIGLU, bf16 output)
+        __syncthreads();
+        char* img = smem + wave * 16384;
+        const T* bias = reinterpret_cast<const T*>(p.bias);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = j * 16 + 4 * q4;               // column inside the wave's 64
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n0 + wn * 64 + nl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bv[k] = (float)b4[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = i * 16 + c16;
+                bf16x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc16[i][j][k] + bv[k];
+                    if (p.act == AFHIP_ACT_GELU) v = gelu_act<T>(v);
+                    o[k] = (bf16)v;
+                }
+                *reinterpret_cast<bf16x4*>(img + row * 128 + (((nl >> 3) ^ swz(row)) << 4) + ((nl >> 2) & 1) * 8) = o;
+            }
+        }
+        __syncthreads();
+        const T* res = reinterpret_cast<const T*>(p.res);
+        T* C = reinterpret_cast<T*>(p.C);
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int idx = t * 64 + lane;
+            const int row = idx >> 3, chx = idx & 7;
+            const int m = m0 + wm * 128 + row;
+            if (m >= p.M) continue;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 128 + ((chx ^ swz(row)) << 4));
+            const long long col = n0 + wn * 64 + chx * 8;
+            if (res) {
+                const long long rrow = (long long)(p.res_row_mod > 0 ? (m % p.res_row_mod) : m) * p.ldres;
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + rrow + col);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)r[k]);
+            }
+            *reinterpret_cast<bf16x8*>(C + (long long)m * p.ldc + col) = v;
+        }
+        return;
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -360,13 +456,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_quarter(0, 0, i);
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile: barrier, then MFMA groups with the next tile's LDS-DMA issued inside the first two groups.  The body
+    // is branch-free (MORE is a compile-time flag, the last tile is peeled) so the scheduler can overlap the LDS reads of
+    // group kc+1 with the MFMAs of group kc.
+    auto k_tile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         __syncthreads();                      // emits s_waitcnt vmcnt(0) for the pending LDS-DMA, then s_barrier
-        const bool more = kt + 1 < nk;
         const char* sa = smem + (kt & 1) * 2 * TILE2_BYTES;
         const char* sw = sa + TILE2_BYTES;
-        // the next tile's LDS-DMA is issued in the first half of this tile's MFMA groups, two quarters per group: late
-        // enough not to delay the first MFMAs behind a burst of DMA issues, early enough to land before the barrier
         constexpr int DMA_GROUPS = KC >= 2 ? 2 : 1;
         constexpr int QPG = 4 / DMA_GROUPS;
 #pragma unroll
@@ -376,16 +473,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             for (int i = 0; i < 4; ++i) fa[i] = load_frag(sa, wm * 128 + i * 32 + fr, kc);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = load_frag(sw, wn * 64 + j * 32 + fr, kc);
-            if (more && kc < DMA_GROUPS) {
+            if constexpr (MORE) {
+                if (kc < DMA_GROUPS) {
 #pragma unroll
-                for (int qq = 0; qq < QPG; ++qq) dma_quarter(kt + 1, (kt + 1) & 1, kc * QPG + qq);
+                    for (int qq = 0; qq < QPG; ++qq) dma_quarter(kt + 1, (kt + 1) & 1, kc * QPG + qq);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[j], fa[i], acc[i][j]);
         }
-    }
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) k_tile(kt, std::true_type{});
+    k_tile(nk - 1, std::false_type{});
     if constexpr (SZ == 2) {
         if (p.vec == 1 && p.act != AFHIP_ACT_SWIGLU && !p.out_f32) {
             // ---- epilogue through LDS: every wave owns a [128 rows x 64 cols] bf16 image (16 KiB, 128-B rows,
@@ -459,6 +560,14 @@ struct GemmProf {
 static bool force_small_tile() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("AFHIP_GEMM_SMALL_TILE"); v = (e && e[0] == '1') ? 1 : 0; }   // A/B switch for benchmarking
+    return v == 1;
+}
+
+static bool use_mfma16() {
+    // A/B switch: the 16x16x32 body measured within +-3 % of the 32x32x16 one on MI355X (tools/gemm_bench.py), so the
+    // 32x32 body (shared with the f32 path) stays the default
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AFHIP_GEMM_MFMA16"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
 
@@ -554,8 +663,12 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     if (big) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<float, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<float, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
     }
@@ -563,8 +676,20 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     const int slot = g_prof.n;
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
     if (big) {
-        if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(gemm256_kernel<bf16>, dim3((unsigned)nwg), dim3(512), lds, s, p);
-        else hipLaunchKernelGGL(gemm256_kernel<float>, dim3((unsigned)nwg), dim3(512), lds, s, p);
+        const bool conv = a->conv_C > 0;
+        const bool mf16 = a->dtype == AFHIP_BF16 && p.vec == 1 && a->act != AFHIP_ACT_SWIGLU && !a->out_f32 && use_mfma16();
+        if (a->dtype == AFHIP_BF16) {
+            if (mf16) {
+                if (conv) hipLaunchKernelGGL((gemm256_kernel<bf16, true, 16>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+                else hipLaunchKernelGGL((gemm256_kernel<bf16, false, 16>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+            } else {
+                if (conv) hipLaunchKernelGGL((gemm256_kernel<bf16, true, 32>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+                else hipLaunchKernelGGL((gemm256_kernel<bf16, false, 32>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+            }
+        } else {
+            if (conv) hipLaunchKernelGGL((gemm256_kernel<float, true, 32>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+            else hipLaunchKernelGGL((gemm256_kernel<float, false, 32>), dim3((unsigned)nwg), dim3(512), lds, s, p);
+        }
     } else {
         if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(gemm_kernel<bf16>, dim3((unsigned)nwg), dim3(256), lds, s, p);
         else hipLaunchKernelGGL(gemm_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, s, p);

@@ -15,10 +15,12 @@ struct LlmWs {
     char* att;   // [rows, nq hd]
     char* act;   // [rows, 2*inter] (skinny path) / [rows, inter]
     char* act2;  // [rows, inter]
+    char* part;  // decode attention partials (T == 1)
+    size_t part_bytes;
     size_t total;
 };
 
-LlmWs carve(const afhip_llm_weights* w, int rows, char* base) {
+LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
     const size_t sz = dtype_size(w->dtype);
     const size_t H = w->hidden, qw = (size_t)(w->n_q + 2 * w->n_kv) * w->hd;
     LlmWs ws;
@@ -30,6 +32,9 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base) {
     ws.att = take((size_t)rows * w->n_q * w->hd * sz);
     ws.act = take((size_t)rows * 2 * w->inter * sz);
     ws.act2 = take((size_t)rows * w->inter * sz);
+    // decode partials: ceil(ctx/256) splits x rows(B) x n_kv x 32 x (hd+2) f32 (only used when T == 1)
+    ws.part_bytes = max_ctx > 0 ? (size_t)((max_ctx + 255) / 256) * rows * w->n_kv * 32 * (w->hd + 2) * sizeof(float) : 0;
+    ws.part = take(ws.part_bytes);
     ws.total = off;
     return ws;
 }
@@ -123,11 +128,11 @@ __global__ void decode_update_kernel(const int64_t* __restrict__ tok, int64_t* _
 
 }  // namespace
 
-extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T) {
+extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T, int max_ctx) {
     if (!w || B <= 0 || T <= 0) return 0;
     // forward scratch + head scratch (n_stream rows of hidden per token row, f32 logits for one decode step, ids, token)
     const size_t rows = (size_t)B * T;
-    size_t tot = carve(w, (int)rows, nullptr).total;
+    size_t tot = carve(w, (int)rows, nullptr, T == 1 ? max_ctx : 0).total;
     tot += align256(rows * w->n_stream * w->hidden * dtype_size(w->dtype));
     tot += align256((size_t)B * w->vocab * sizeof(float));
     tot += align256((size_t)B * w->n_stream * sizeof(int64_t)) + align256((size_t)B * sizeof(int64_t));
@@ -146,7 +151,7 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
     AFHIP_CHECK(pos0 + T <= cache->cap, "afhip_llm_forward: positions [%d,%d) exceed KV capacity %d", pos0, pos0 + T, cache->cap);
     AFHIP_CHECK(pos0 + T <= w->rope_max_pos, "afhip_llm_forward: positions exceed rope table %d", w->rope_max_pos);
     const int rows = B * T;
-    const LlmWs ws = carve(w, rows, (char*)workspace);
+    const LlmWs ws = carve(w, rows, (char*)workspace, T == 1 ? cache->cap : 0);
     if (workspace_bytes < ws.total) {
         afhip_set_error("afhip_llm_forward: workspace %zu < required %zu bytes", workspace_bytes, ws.total);
         return AFHIP_ERR_WORKSPACE;
@@ -169,11 +174,26 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         if ((rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
         afhip_attn_args a;
         a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
-        a.B = B; a.Tq = T; a.Tk = pos0 + T; a.n_q = nq; a.n_kv = nkv; a.hd = hd;
-        a.ld_q = qw; a.ld_kv = hd; a.ld_o = nq * hd;
-        a.q_batch_stride = (long long)T * qw; a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.o_batch_stride = (long long)T * nq * hd;
-        a.q_head_stride = hd; a.kv_head_stride = (long long)cache->cap * hd;
-        a.causal = 1; a.q_pos0 = pos0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        a.hd = hd; a.ld_kv = hd;
+        a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.kv_head_stride = (long long)cache->cap * hd;
+        a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        a.B = B; a.Tk = pos0 + T;
+        const int rep = nq / nkv;
+        if (T == 1 && rep <= 32) {
+            // decode: the `rep` query heads that share a kv head are the query rows of one workgroup, so each K/V byte is
+            // streamed once per group; the context is split into 256-key ranges over workgroups and merged (flash-decoding)
+            a.Tq = rep; a.n_q = nkv; a.n_kv = nkv;
+            a.ld_q = hd; a.q_head_stride = (long long)rep * hd; a.q_batch_stride = qw;
+            a.ld_o = hd; a.o_head_stride = (long long)rep * hd; a.o_batch_stride = (long long)nq * hd;
+            a.causal = 0; a.q_pos0 = 0;
+            a.key_split = 256; a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
+        } else {
+            a.Tq = T; a.n_q = nq; a.n_kv = nkv;
+            a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;
+            a.ld_o = nq * hd; a.o_head_stride = 0; a.o_batch_stride = (long long)T * nq * hd;
+            a.causal = 1; a.q_pos0 = pos0;
+            a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
+        }
         if ((rc = afhip_attention(&a, s))) return rc;
         if ((rc = gemm_any(ws.att, w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         if ((rc = afhip_rmsnorm(ws.x, w->ln2_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
@@ -230,7 +250,7 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     AFHIP_CHECK(w && cache && st && workspace, "afhip_llm_decode_step: null pointer");
     AFHIP_CHECK(st->prev_token && st->out_tokens && st->finished_at && st->allowed && st->n_iv > 0, "afhip_llm_decode_step: bad state");
     AFHIP_CHECK(B > 0 && step >= 0, "afhip_llm_decode_step: bad B/step");
-    const size_t need = afhip_llm_workspace_bytes(w, B, 1);
+    const size_t need = afhip_llm_workspace_bytes(w, B, 1, cache->cap);
     if (workspace_bytes < need) {
         afhip_set_error("afhip_llm_decode_step: workspace %zu < required %zu bytes", workspace_bytes, need);
         return AFHIP_ERR_WORKSPACE;
@@ -239,7 +259,8 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     const int dt = w->dtype, H = w->hidden, S = w->n_stream;
     const size_t sz = dtype_size(dt);
     char* base = (char*)workspace;
-    size_t off = carve(w, B, nullptr).total;
+    const size_t fwd_bytes = carve(w, B, nullptr, cache->cap).total;
+    size_t off = fwd_bytes;
     char* hs = base + off; off += align256((size_t)B * S * H * sz);
     float* logits = (float*)(base + off); off += align256((size_t)B * w->vocab * sizeof(float));
     int64_t* ids = (int64_t*)(base + off); off += align256((size_t)B * S * sizeof(int64_t));
@@ -250,7 +271,7 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);
     AFHIP_LAUNCH_CHECK();
     if ((rc = afhip_embed_sum(ids, w->embed, emb, B, S, H, w->vocab, dt, s))) return rc;
-    if ((rc = afhip_llm_forward(w, emb, B, 1, pos, cache, hid, workspace, carve(w, B, nullptr).total, s))) return rc;
+    if ((rc = afhip_llm_forward(w, emb, B, 1, pos, cache, hid, workspace, fwd_bytes, s))) return rc;
     if ((rc = afhip_lm_head(w, hid, B, 1, logits, hs, align256((size_t)B * S * H * sz), s))) return rc;
     if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, s))) return rc;
     hipLaunchKernelGGL(decode_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, (const int64_t*)tok, st->prev_token, st->out_tokens,

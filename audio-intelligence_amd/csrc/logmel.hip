@@ -26,6 +26,7 @@ constexpr int BINPAD = 224;               // 201 bins padded to 7 tiles of 32
 constexpr int HOPROW = HOP + 1;           // LDS row pitch (floats)
 constexpr int NHOPROWS = FT + 3;          // hops touched by 64 frames: 63 + ceil(400/160) = 66 (+1 slack)
 constexpr int PROW = BINPAD + 1;          // LDS pitch of the power tile
+constexpr int MAIN_FLOATS = (NHOPROWS * HOPROW > FT * PROW) ? NHOPROWS * HOPROW : FT * PROW;
 
 // device-side constant tables (one buffer, built by afhip_log_mel_tables_host)
 struct Tables {
@@ -33,9 +34,12 @@ struct Tables {
     static constexpr size_t COS = 0;                                  // [BINPAD][KPAD]
     static constexpr size_t SIN = COS + (size_t)BINPAD * KPAD;        // [BINPAD][KPAD] (already negated)
     static constexpr size_t WIN = SIN + (size_t)BINPAD * KPAD;        // [KPAD] window w[n], n = i+1 (0 beyond 200)
-    static constexpr size_t FILT = WIN + KPAD;                        // [NBIN][NMEL]
+    static constexpr size_t FILT = WIN + KPAD;                        // [NBIN][NMEL] dense bank (kept for reference / tests)
     static constexpr size_t BAND = FILT + (size_t)NBIN * NMEL;        // [NMEL][2] int32 (first bin, count)
-    static constexpr size_t TOTAL = BAND + 2 * NMEL;
+    static constexpr size_t COFF = BAND + 2 * NMEL;                   // [NMEL] int32 offset of the mel's weights in CW
+    static constexpr size_t CW = COFF + NMEL;                         // [CWMAX] non-zero weights, mel-major
+    static constexpr size_t CWMAX = 512;
+    static constexpr size_t TOTAL = CW + CWMAX;
 };
 
 __device__ __forceinline__ int float_order_key(float f) {
@@ -49,26 +53,66 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
                                                     int* __restrict__ clipmax) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);          // [NHOPROWS][HOPROW] samples, later [FT][PROW] power
+    float* cw = xs + MAIN_FLOATS;                            // [CWMAX] compact mel weights
+    int* cband = reinterpret_cast<int*>(cw + Tables::CWMAX); // [NMEL][3] first bin, count, offset
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * FT;
     const float* w = wav + (long long)b * wav_stride;
 
-    // ---- stage samples: padded index p = t0*160 + s, original index i = p - 200 (reflect) ----
-    const int nstage = (FT - 1) * HOP + NFFT;
-    for (int s = tid; s < nstage; s += 256) {
-        int i = t0 * HOP + s - NFFT / 2;
-        if (i < 0) i = -i;
-        if (i >= NSAMP) i = 2 * (NSAMP - 1) - i;
-        float v = 0.f;
-        if (i >= 0 && i < n_samples) v = w[i];
-        xs[(s / HOP) * HOPROW + (s % HOP)] = v;
+    for (int i = tid; i < (int)Tables::CWMAX; i += 256) cw[i] = tab[Tables::CW + i];
+    for (int i = tid; i < NMEL; i += 256) {
+        const int* band_g = reinterpret_cast<const int*>(tab + Tables::BAND);
+        cband[3 * i] = band_g[2 * i];
+        cband[3 * i + 1] = band_g[2 * i + 1];
+        cband[3 * i + 2] = reinterpret_cast<const int*>(tab + Tables::COFF)[i];
+    }
+    // ---- stage samples: padded index p = t0*160 + s, original index i = p - 200 (reflect at both clip ends, zero
+    //      beyond n_samples).  All loads of a thread are issued before the first LDS store (11 x 16 B in flight per lane);
+    //      workgroups that touch neither clip end nor the zero-padded tail take aligned float4 loads. ----
+    constexpr int NSTAGE = (FT - 1) * HOP + NFFT;          // 10480 samples = 2620 float4
+    constexpr int NV4 = NSTAGE / 4, V4_PER_THREAD = (NV4 + 255) / 256;
+    const int ibase = t0 * HOP - NFFT / 2;                  // multiple of 8: float4 loads stay 16-byte aligned
+    const bool interior = ibase >= 0 && ibase + NSTAGE <= n_samples && (n_samples <= NSAMP) && ((wav_stride & 3) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
+    f32x4 sv[V4_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < V4_PER_THREAD; ++u) {
+        const int v = tid + 256 * u;
+        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (v < NV4) {
+            if (interior) {
+                sv[u] = *reinterpret_cast<const f32x4*>(w + ibase + 4 * v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int i = ibase + 4 * v + e;
+                    if (i < 0) i = -i;
+                    if (i >= NSAMP) i = 2 * (NSAMP - 1) - i;
+                    if (i >= 0 && i < n_samples) sv[u][e] = w[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < V4_PER_THREAD; ++u) {
+        const int v = tid + 256 * u;
+        if (v < NV4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sidx = 4 * v + e;
+                xs[(sidx / HOP) * HOPROW + (sidx % HOP)] = sv[u][e];
+            }
+        }
     }
     __syncthreads();
 
     // ---- folded DFT on MFMA: this wave owns bin tiles j = wave and wave + 4 (7 tiles in all) ----
     const int nj = (wave + 4 < 7) ? 2 : 1;
+    const float* cosT = tab + Tables::COS;
+    const float* sinT = tab + Tables::SIN;
+    const float* win = tab + Tables::WIN;
     f32x16 re[2][2], im[2][2];  // [m tile][bin tile]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -77,28 +121,33 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
 #pragma unroll
             for (int e = 0; e < 16; ++e) { re[a][c][e] = 0.f; im[a][c][e] = 0.f; }
 
-    const float* cosT = tab + Tables::COS;
-    const float* sinT = tab + Tables::SIN;
-    const float* win = tab + Tables::WIN;
-    for (int step = 0; step < KPAD / 16; ++step) {
-        const int i0 = step * 16 + fh * 8;             // first folded index of this lane's 8 elements
-        // twiddle fragments (B operand): row = bin, 8 consecutive n
-        f32x8 fc[2], fs[2];
+    // twiddle fragments (B operand): row = bin, 8 consecutive n per lane.  They stream from L2 and the wave is alone on
+    // its SIMD (the accumulators take most of the register file), so the fragments of step s+1 are fetched into a second
+    // register set while the MFMAs of step s run.
+    f32x8 fc[2], fs[2], nfc[2], nfs[2];
+    auto load_tw = [&](int step, f32x8 (&c8)[2], f32x8 (&s8)[2]) {
+        const int ii = step * 16 + fh * 8;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int bin = (wave + 4 * c) * 32 + fr;
             if (c < nj) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosT + (size_t)bin * KPAD + i0);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + (size_t)bin * KPAD + i0 + 4);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinT + (size_t)bin * KPAD + i0);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sinT + (size_t)bin * KPAD + i0 + 4);
-                fc[c] = f32x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                fs[c] = f32x8{s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosT + (size_t)bin * KPAD + ii);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + (size_t)bin * KPAD + ii + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinT + (size_t)bin * KPAD + ii);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sinT + (size_t)bin * KPAD + ii + 4);
+                c8[c] = f32x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                s8[c] = f32x8{s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
             } else {
-                fc[c] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-                fs[c] = fc[c];
+                c8[c] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+                s8[c] = c8[c];
             }
         }
+    };
+    load_tw(0, fc, fs);
+#pragma unroll 1
+    for (int step = 0; step < KPAD / 16; ++step) {
+        const int i0 = step * 16 + fh * 8;             // first folded index of this lane's 8 elements
+        if (step + 1 < KPAD / 16) load_tw(step + 1, nfc, nfs);
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(win + i0);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(win + i0 + 4);
         const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
@@ -125,6 +174,8 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { fc[c] = nfc[c]; fs[c] = nfs[c]; }
     }
     __syncthreads();   // everyone is done with the samples: reuse LDS for the power tile
 
@@ -145,20 +196,20 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
         }
     __syncthreads();
 
-    // ---- banded mel + log10; scratch is [B][3000][128] f32 ----
-    const float* filt = tab + Tables::FILT;
-    const int* band = reinterpret_cast<const int*>(tab + Tables::BAND);
+    // ---- banded mel + log10 (weights and band table in LDS: no dependent global loads); scratch is [B][3000][128] f32 ----
     float mx = -INFINITY;
-    for (int idx = tid; idx < FT * NMEL; idx += 256) {
-        const int f = idx >> 7, m = idx & 127;
-        const int t = t0 + f;
-        if (t >= NFRAMES) break;
-        const int k0 = band[2 * m], kc = band[2 * m + 1];
-        float acc = 0.f;
-        for (int k = k0; k < k0 + kc; ++k) acc += filt[k * NMEL + m] * pw[f * PROW + k];
-        const float v = log10f(fmaxf(acc, 1e-10f));
-        scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
-        mx = fmaxf(mx, v);
+    {
+        const int m = tid & 127;
+        const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
+        for (int f = tid >> 7; f < FT; f += 2) {
+            const int t = t0 + f;
+            if (t >= NFRAMES) break;
+            float acc = 0.f;
+            for (int k = 0; k < kc; ++k) acc += cw[wo + k] * pw[f * PROW + k0 + k];
+            const float v = log10f(fmaxf(acc, 1e-10f));
+            scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
+            mx = fmaxf(mx, v);
+        }
     }
     mx = wave_max(mx);
     if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
@@ -224,6 +275,15 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
         band[2 * m] = lo < 0 ? 0 : lo;
         band[2 * m + 1] = lo < 0 ? 0 : hi - lo + 1;
     }
+    int* coff = reinterpret_cast<int*>(t + Tables::COFF);
+    int off = 0;
+    for (int m = 0; m < NMEL; ++m) {
+        coff[m] = off;
+        for (int k = 0; k < band[2 * m + 1]; ++k) {
+            AFHIP_CHECK(off < (int)Tables::CWMAX, "afhip_log_mel_tables_host: filter bank has more than %d band entries", (int)Tables::CWMAX);
+            t[Tables::CW + off++] = filters_host[(band[2 * m] + k) * NMEL + m];
+        }
+    }
     return 0;
 }
 
@@ -245,7 +305,7 @@ extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_str
     int* clipmax = reinterpret_cast<int*>(workspace);
     float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * sizeof(int) + 255) / 256 * 256);
     hipLaunchKernelGGL(logmel_init_max, dim3(cdiv(B, 256)), dim3(256), 0, s, clipmax, B);
-    const size_t lds1 = sizeof(float) * (size_t)((NHOPROWS * HOPROW > FT * PROW) ? NHOPROWS * HOPROW : FT * PROW);
+    const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL);
     hipLaunchKernelGGL(logmel_pass1, dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
                        tables, scratch, clipmax);
     const dim3 g2(cdiv(NFRAMES, 32), B);

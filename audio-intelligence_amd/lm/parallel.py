@@ -248,9 +248,9 @@ class ParallelLLM(nn.Module):
         self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv)
         return self._packed
 
-    def _workspace(self, B, T):
+    def _workspace(self, B, T, max_ctx=0):
         lib = L.lib()
-        need = lib.afhip_llm_workspace_bytes(C.byref(self.pack().w), B, T)
+        need = lib.afhip_llm_workspace_bytes(C.byref(self.pack().w), B, T, max_ctx)
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -328,7 +328,7 @@ class ParallelLLM(nn.Module):
         pk = self.pack(cache.cap)
         x = input_embeds.to(self.dtype).contiguous()
         hid = torch.empty_like(x)
-        ws = self._workspace(B, T)
+        ws = self._workspace(B, T, cache.cap)
         cs = cache.struct()
         L.check(lib.afhip_llm_forward(C.byref(pk.w), L.ptr(x), B, T, pos0, C.byref(cs), L.ptr(hid), L.ptr(ws), ws.numel(), L.stream_ptr()))
         cache.length = pos0 + T
@@ -380,7 +380,7 @@ class ParallelLLM(nn.Module):
         st = L.DecodeState()
         st.prev_token, st.out_tokens, st.finished_at = prev.data_ptr(), out_tokens.data_ptr(), finished.data_ptr()
         st.allowed, st.n_iv, st.eos_id, st.eot_id = iv.data_ptr(), iv.shape[0], self.eos_token_id, self.eot_token_id
-        ws = self._workspace(B, 1)
+        ws = self._workspace(B, 1, cache.cap)
         cs = cache.struct()
         n_done = max_step
         for step in range(max_step):

@@ -165,3 +165,31 @@ def rope_kv(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, 
     L.check(lib.afhip_rope_kv(L.ptr(qkv), ld, L.ptr(cos), L.ptr(sin), pos0, L.ptr(k_cache), L.ptr(v_cache), B, T, n_q, n_kv, hd,
                               cap, cos.shape[0], L.dtype_code(qkv.dtype), L.stream_ptr()))
     return qkv
+
+
+def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int, tk: int,
+                     key_split: int = 256, ld_q: Optional[int] = None):
+    """One new token per sequence: q [B, >= n_q*hd] (row stride ld_q) against the first `tk` positions of a KV cache
+    [B,n_kv,cap,hd].  The q heads of a kv group become the query rows of one workgroup and the context is split into
+    `key_split`-key ranges merged by a second pass (flash-decoding)."""
+    lib = L.lib()
+    _chk(q, "attention_decode.q")
+    B = q.shape[0]
+    cap, hd = k_cache.shape[2], k_cache.shape[3]
+    rep = n_q // n_kv
+    out = torch.empty((B, n_q * hd), dtype=q.dtype, device=q.device)
+    n_split = (tk + key_split - 1) // key_split
+    part = torch.empty(n_split * B * n_kv * 32 * (hd + 2), dtype=torch.float32, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr()
+    a.key_len = None
+    a.B, a.Tq, a.Tk, a.n_q, a.n_kv, a.hd = B, rep, tk, n_kv, n_kv, hd
+    a.ld_q, a.ld_kv, a.ld_o = hd, hd, hd
+    a.q_batch_stride = ld_q if ld_q is not None else q.stride(0)
+    a.kv_batch_stride = n_kv * cap * hd
+    a.o_batch_stride = n_q * hd
+    a.q_head_stride, a.kv_head_stride, a.o_head_stride = rep * hd, cap * hd, rep * hd
+    a.causal, a.q_pos0, a.scale, a.dtype = 0, 0, 1.0 / math.sqrt(hd), L.dtype_code(q.dtype)
+    a.key_split, a.partial_ws, a.partial_ws_bytes = key_split, part.data_ptr(), part.numel() * 4
+    L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
+    return out

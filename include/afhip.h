@@ -117,6 +117,8 @@ int afhip_transpose_cast(const void* x, void* y, int B, int R, int C, int in_dty
  *   q[b,t,h,:] = q + b*q_batch_stride + t*ld_q + h*q_head_stride (elements); k/v likewise with the kv strides
  *   (packed qkv rows and the [B,n_kv,cap,hd] cache are both expressible); out [B,Tq,n_q*hd], row stride ld_o.
  *   key_len[b] (may be NULL): keys >= key_len[b] are masked.  causal: key j visible to query i iff j <= i + q_pos0.
+ *   Decode (one new token per sequence): pass the q heads of one kv group as the "query rows" (Tq = n_q/n_kv,
+ *   ld_q = hd, q_head_stride = Tq*hd, n_q = n_kv) so a workgroup streams each K/V byte once for the whole group.
  */
 typedef struct {
     const void* q;
@@ -131,6 +133,11 @@ typedef struct {
     int causal, q_pos0;
     float scale;
     int dtype;
+    long long o_head_stride;   /* elements between output heads; 0 = hd */
+    int key_split;             /* > 0: split the keys into ranges of this many (multiple of 64) over workgroups and merge
+                                  the partial softmaxes in a second pass: for decode-size query counts (Tq <= 32, causal 0) */
+    void* partial_ws;          /* f32 scratch, ceil(Tk/key_split) * B * n_q * 32 * (hd + 2) * 4 bytes */
+    size_t partial_ws_bytes;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 
@@ -190,7 +197,8 @@ typedef struct {
     int cap, B;
 } afhip_kv_cache;
 
-size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T);
+/* max_ctx: KV-cache capacity the T == 1 (decode) calls will run against (sizes the split-context attention partials) */
+size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T, int max_ctx);
 /* Forward T tokens per sequence from embeddings x [B,T,hidden] starting at cache position pos0; appends K/V.
  * hidden_out [B,T,hidden] = final-normed hidden states (model.norm applied). */
 int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,

@@ -85,8 +85,12 @@ def test_log_mel_constant_tables_host():
     np.testing.assert_allclose(win[:200], 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1, 201) / 400), atol=1e-7)
     off = 2 * BP * KP + KP
     np.testing.assert_array_equal(host[off: off + 201 * 128].reshape(201, 128), filt)
-    band = host[off + 201 * 128:].view(np.int32).reshape(128, 2)
+    b0 = off + 201 * 128
+    band = host[b0: b0 + 256].view(np.int32).reshape(128, 2)
+    coff = host[b0 + 256: b0 + 384].view(np.int32)
+    cw = host[b0 + 384: b0 + 384 + 512]
     for m in range(128):
         nz = np.nonzero(filt[:, m])[0]
         assert band[m, 0] == nz[0] and band[m, 1] == nz[-1] - nz[0] + 1
+        np.testing.assert_array_equal(cw[coff[m]: coff[m] + band[m, 1]], filt[band[m, 0]: band[m, 0] + band[m, 1], m])
     assert lib.afhip_log_mel_workspace_bytes(32) >= 32 * 3000 * 128 * 4

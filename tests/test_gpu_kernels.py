@@ -318,3 +318,19 @@ def test_gemm_big_tile_path(dt):
     g = _rand(I, H, seed=50, scale=0.1).to(dt); u = _rand(I, H, seed=51, scale=0.1).to(dt)
     packed = torch.stack([g.view(I // 32, 32, H), u.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous().to(_dev())
     _check(ops.gemm(xd, packed, act=L.ACT_SWIGLU), F.silu(xf @ g.float().T) * (xf @ u.float().T), *tol, "big swiglu")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nq,nkv,hd,tk", [(28, 4, 128, 801), (12, 2, 64, 300), (8, 8, 64, 64), (12, 2, 64, 1)])
+def test_attention_decode_split_context(dt, nq, nkv, hd, tk):
+    """decode attention: GQA group = query rows of one workgroup, context split into key ranges + merge pass"""
+    from audio_intelligence_amd import ops
+    B, cap = 3, 1024
+    qd, qf = _q(_rand(B, nq * hd, seed=61), dt)
+    kd, kf = _q(_rand(B, nkv, cap, hd, seed=62), dt)
+    vd, vf = _q(_rand(B, nkv, cap, hd, seed=63), dt)
+    out = ops.attention_decode(qd, kd, vd, nq, nkv, tk)
+    ref = _ref_attention(qf.reshape(B, 1, nq, hd), kf[:, :, :tk].permute(0, 2, 1, 3), vf[:, :, :tk].permute(0, 2, 1, 3))
+    _check(out, ref.reshape(B, nq * hd), *_tol(dt, (2e-5, 1e-4), (2e-2, 2e-2)), f"decode attention tk={tk}")
+    out2 = ops.attention_decode(qd, kd, vd, nq, nkv, tk, key_split=64)
+    _check(out2, ref.reshape(B, nq * hd), *_tol(dt, (2e-5, 1e-4), (2e-2, 2e-2)), f"decode attention tk={tk} split 64")
