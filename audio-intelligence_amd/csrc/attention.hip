@@ -40,6 +40,16 @@ template <int ROWBYTES> __device__ __forceinline__ int rswz(int row) {
     else return row & 7;
 }
 
+// bf16 V tiles stay row-major [key][d] in LDS and are consumed transposed by ds_read_b64_tr_b16: a 16-lane group reads a
+// 4-key x 16-d block (lane 4q+p supplies the address of key q, columns 4p..4p+3; lane i receives column i, key q in
+// element q).  A 32-lane half therefore touches 4 keys x 64 B; moving that 64-B region by the key index keeps the 4 keys
+// on different banks: 128-B rows (two rows per bank row) flip it on bit 1 of the key, 256-B rows rotate it by key & 3.
+template <int ROWBYTES> __device__ __forceinline__ int vtrswz(int row) {
+    if constexpr (ROWBYTES == 128) return ((row >> 1) & 1) << 2;
+    else return (row & 3) << 2;
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     constexpr int SZ = sizeof(T);
@@ -120,16 +130,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             const int c = tid + 256 * i;
             const int row = c / KCPR, cc = c % KCPR;
             st16(Ks + row * KROWB + ((cc ^ rswz<KROWB>(row)) << 4), rk[i]);
-            // transpose V chunk: element e of this chunk is V[key=row][d = cc*EPC + e] -> Vt[d][key]
-            const int kch = row / EPC, kin = row % EPC;
+            if constexpr (SZ == 2) {
+                // bf16: V stays row-major [key][d] (read back transposed by ds_read_b64_tr_b16)
+                st16(Vt + row * KROWB + ((cc ^ vtrswz<KROWB>(row)) << 4), rv[i]);
+            } else {
+                // f32 (parity mode): transpose while storing, element e of this chunk is V[key=row][d = cc*EPC + e] -> Vt[d][key]
+                const int kch = row / EPC, kin = row % EPC;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int d = cc * EPC + e;
-                char* dst = Vt + d * VROWB + ((kch ^ rswz<VROWB>(d)) << 4) + kin * SZ;
-                if constexpr (SZ == 2) {
-                    const uint32_t wv = rv[i][e >> 1];
-                    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
-                } else {
+                for (int e = 0; e < EPC; ++e) {
+                    const int d = cc * EPC + e;
+                    char* dst = Vt + d * VROWB + ((kch ^ rswz<VROWB>(d)) << 4) + kin * SZ;
                     *reinterpret_cast<uint32_t*>(dst) = rv[i][e];
                 }
             }
@@ -222,8 +232,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 const int vrow = dt * 32 + fr;
                 typename Frag8<T>::type vf;
                 if constexpr (SZ == 2) {
-                    const int ch = s * 2 + fh;
-                    vf = *reinterpret_cast<const bf16x8*>(Vt + vrow * VROWB + ((ch ^ rswz<VROWB>(vrow)) << 4));
+                    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, gsel = (lane >> 4) & 1;
+                    const int col = dt * 32 + gsel * 16 + tp * 4;          // first of this lane's 4 address columns
+                    const int key0 = s * 16 + fh * 8 + tq, key1 = key0 + 4;
+                    const char* a0 = Vt + key0 * KROWB + (((col >> 3) ^ vtrswz<KROWB>(key0)) << 4) + (col & 7) * 2;
+                    const char* a1 = Vt + key1 * KROWB + (((col >> 3) ^ vtrswz<KROWB>(key1)) << 4) + (col & 7) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 both = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    vf = __builtin_bit_cast(bf16x8, both);
                 } else {
                     const int ch = s * 4 + fh * 2;
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(Vt + vrow * VROWB + ((ch ^ rswz<VROWB>(vrow)) << 4));
