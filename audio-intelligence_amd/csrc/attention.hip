@@ -9,6 +9,7 @@
 // One workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 64 keys staged through LDS with
 // register prefetch.  Same template for bf16 (32x32x16 MFMA) and exact f32 (32x32x2 MFMA) via common.h mma16.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,7 +51,7 @@ template <int ROWBYTES> __device__ __forceinline__ int vtrswz(int row) {
 }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int HD>
+template <typename T, int HD, int NBUF>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     constexpr int SZ = sizeof(T);
     constexpr int KROWB = HD * SZ;             // bytes per K row in LDS
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     constexpr int EPC = 16 / SZ;               // elements per 16-B chunk
     constexpr int DSTEPS = HD / 16, DT = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_BYTES = 2 * KT * KROWB;   // K tile + V tile; two stages, one barrier per key tile
     char* Ks = smem;
     char* Vt = smem + KT * KROWB;
 
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             rv[i] = ld16(vb + off);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        char* Ks = smem + buf * STAGE_BYTES;
+        char* Vt = Ks + KT * KROWB;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int c = tid + 256 * i;
@@ -148,12 +152,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 
     if (ntiles > tbeg) {
         load_tile(tbeg);
-        store_tile();
+        store_tile(0);
     }
     __syncthreads();
 
     for (int t = tbeg; t < ntiles; ++t) {
         const int k0 = t * KT;
+        const int cur = NBUF == 2 ? ((t - tbeg) & 1) : 0;
+        Ks = smem + cur * STAGE_BYTES;
+        Vt = Ks + KT * KROWB;
         if (t + 1 < ntiles) load_tile(t + 1);
 
         // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
@@ -252,9 +259,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
 
-        __syncthreads();
-        if (t + 1 < ntiles) store_tile();
-        __syncthreads();
+        if constexpr (NBUF == 2) {
+            if (t + 1 < ntiles) store_tile(cur ^ 1);   // the other stage: its last readers passed the previous barrier
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (t + 1 < ntiles) store_tile(0);
+            __syncthreads();
+        }
     }
 
     // ---- normalise and write O[query, d] (or the unnormalised partial of this key range) ----
@@ -365,14 +377,29 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         p.part_ml = p.part_o + (size_t)n_split * a->B * a->n_q * 32 * a->hd;
     }
     const dim3 grid(a->key_split > 0 ? n_split : cdiv(a->Tq, QT), a->n_q, a->B), block(256);
-    const size_t lds = 2 * (size_t)KT * a->hd * sz;
-    if (a->dtype == AFHIP_BF16) {
-        if (a->hd == 64) hipLaunchKernelGGL((attn_kernel<bf16, 64>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, lds, s, p);
-    } else {
-        if (a->hd == 64) hipLaunchKernelGGL((attn_kernel<float, 64>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, lds, s, p);
+    static int nbuf = -1;
+    if (nbuf < 0) { const char* e = getenv("AFHIP_ATTN_NBUF"); nbuf = (e && e[0] == '1') ? 1 : 2; }   // A/B switch
+    const size_t lds = (size_t)nbuf * 2 * KT * a->hd * sz;     // stages of (K tile + V tile)
+    {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 2);
+            (void)hipFuncSetAttribute((const void*)attn_kernel<float, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 64 * 4);
+            (void)hipFuncSetAttribute((const void*)attn_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 4);
+            attr_done = true;
+        }
     }
+#define AFHIP_ATTN_LAUNCH(TT, HH)                                                                          \
+    do {                                                                                                   \
+        if (nbuf == 2) hipLaunchKernelGGL((attn_kernel<TT, HH, 2>), grid, block, lds, s, p);             \
+        else hipLaunchKernelGGL((attn_kernel<TT, HH, 1>), grid, block, lds, s, p);                        \
+    } while (0)
+    if (a->dtype == AFHIP_BF16) {
+        if (a->hd == 64) AFHIP_ATTN_LAUNCH(bf16, 64); else AFHIP_ATTN_LAUNCH(bf16, 128);
+    } else {
+        if (a->hd == 64) AFHIP_ATTN_LAUNCH(float, 64); else AFHIP_ATTN_LAUNCH(float, 128);
+    }
+#undef AFHIP_ATTN_LAUNCH
     AFHIP_LAUNCH_CHECK();
     if (a->key_split > 0) {
         const dim3 g2(a->B * a->n_q * a->Tq), b2(a->hd);
