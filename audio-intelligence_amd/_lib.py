@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldres", C.c_int),
                 ("dtype", C.c_int), ("act", C.c_int), ("res_row_mod", C.c_int),
                 ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int),
-                ("out_f32", C.c_int)]
+                ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int)]
 
 
 class AttnArgs(C.Structure):

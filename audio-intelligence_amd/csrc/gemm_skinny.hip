@@ -1,37 +1,76 @@
-// Skinny GEMM for decode (M <= 64 rows): C[M,N] = A[M,K] . W[N,K]^T (+bias, +residual).  HBM-bound weight stream:
+// Skinny GEMM for decode (M <= 64 rows): C[M,N] = A'[M,K] . W[N,K]^T (+bias, +residual).  HBM-bound weight stream:
 // W goes straight from global memory into MFMA B-operand registers (no LDS: every weight byte is used once),
 // 32 contiguous bytes per lane per step so that the 4 lanes that share a weight row read one full 128-byte line;
 // the K index inside a step is permuted identically on both operands, which MFMA does not care about.
 //   bf16: step = 64 K = 2 x v_mfma_f32_16x16x32_bf16      f32: step = 32 K = 8 x v_mfma_f32_16x16x4_f32
 // One workgroup = 8 waves = NT 16-row weight tiles; the waves interleave over K steps (wave w takes steps
-// w, w+8, ...) and their partial sums are combined through LDS.  Activations (tiny, L2-resident) are re-read
-// per step; NT = 4 amortises them for wide outputs (gate/up, lm_head), NT = 1 keeps the grid >= 224 workgroups
-// for the 3584-wide projections.
+// w, w+8, ...; two steps of loads in flight) and their partial sums are combined through LDS.  Activations (tiny,
+// L2-resident) are re-read per step; NT = 4 amortises them for wide outputs (gate/up, lm_head), NT = 1 keeps the grid
+// >= 224 workgroups for the 3584-wide projections.
+// Two producer ops of the decoder layer are folded into the A-operand load so they cost no launch and no pass:
+//   A_RMSNORM: A' = x (.) w_ln, the row scale rsqrt(mean(x^2)+eps) is applied to the accumulator at the end
+//              (Qwen2RMSNorm, modeling_qwen2.py:238-252, in front of q/k/v and gate/up);
+//   A_SWIGLU : A' = silu(g) * u read from the 32-row interleaved gate/up buffer (kept for completeness: every workgroup
+//              re-evaluates the activation for its whole K range, so it only pays for very narrow outputs);
+// and SwiGLU can instead be the EPILOGUE of the gate/up GEMM (`swiglu_out`): a NT = 4 workgroup owns exactly one 64-row
+// gate/up block pair, so the K-slice combine emits silu(gate) * up straight into the [M, N/2] activation (modeling_qwen2.py:46-48).
 #include "common.h"
 
 namespace {
+
+enum { A_PLAIN = 0, A_RMSNORM = 1, A_SWIGLU = 2 };
 
 struct SkinnyP {
     const char* A;
     const char* W;
     const char* bias;
     const char* res;
+    const char* norm_w;
     char* C;
     int M, N, K;
     long long lda, ldw, ldc, ldres;
     int out_f32;
+    float norm_eps;
+    int swiglu_out;
 };
 
 template <typename T> struct Step;
 template <> struct Step<bf16> { static constexpr int K = 64; };
 template <> struct Step<float> { static constexpr int K = 32; };
 
-template <typename T, int NT, int MT>
+// 16 bytes = 8 bf16 / 4 f32, viewed as f32 values
+template <typename T> struct Half;
+template <> struct Half<bf16> { static constexpr int N = 8; };
+template <> struct Half<float> { static constexpr int N = 4; };
+
+template <typename T> __device__ __forceinline__ float elem(const u32x4& v, int e);
+template <> __device__ __forceinline__ float elem<bf16>(const u32x4& v, int e) {
+    const uint32_t w = v[e >> 1];
+    return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+template <> __device__ __forceinline__ float elem<float>(const u32x4& v, int e) { return __uint_as_float(v[e]); }
+
+template <typename T> __device__ __forceinline__ u32x4 pack(const float* f);
+template <> __device__ __forceinline__ u32x4 pack<bf16>(const float* f) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)f[i];
+    return __builtin_bit_cast(u32x4, o);
+}
+template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
+    return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+}
+
+template <int NT, int MT> struct StepRegs { u32x4 w0[NT], w1[NT], a0[MT], a1[MT], x0[MT], x1[MT], n0, n1; };
+
+template <typename T, int NT, int MT, int AMODE>
 __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     constexpr int SZ = sizeof(T);
     constexpr int KS = Step<T>::K;
+    constexpr int HN = Half<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);   // [8 waves][NT][MT][64 lanes][4]
+    float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NT][MT][64 lanes][4]
+    float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16] row sums of squares (A_RMSNORM)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     const int n_base = blockIdx.x * (NT * 16);
@@ -41,14 +80,14 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     for (int t = 0; t < NT; ++t) {
         int n = n_base + t * 16 + c16;
         n = n < p.N ? n : p.N - 1;
-        wrow[t] = p.W + (long long)n * p.ldw * SZ + q * 32;
+        wrow[t] = p.W + (long long)n * p.ldw * SZ;
     }
     const char* arow[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         int m = t * 16 + c16;
         m = m < p.M ? m : p.M - 1;
-        arow[t] = p.A + (long long)m * p.lda * SZ + q * 32;
+        arow[t] = p.A + (long long)m * p.lda * SZ;
     }
 
     f32x4 acc[NT][MT];
@@ -56,31 +95,85 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) ss[b] = 0.f;
 
     const int nsteps = p.K / KS;
-    for (int s = wave; s < nsteps; s += 8) {
-        const long long koff = (long long)s * KS * SZ;   // = s * 128 bytes
-        u32x4 w0[NT], w1[NT], a0[MT], a1[MT];
+
+    auto issue = [&](int s, StepRegs<NT, MT>& r) {
+        const long long koff = (long long)s * KS * SZ + q * 32;          // byte offset of this lane's 32 B inside a K row
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { w0[t] = ld16(wrow[t] + koff); w1[t] = ld16(wrow[t] + koff + 16); }
+        for (int t = 0; t < NT; ++t) { r.w0[t] = ld16(wrow[t] + koff); r.w1[t] = ld16(wrow[t] + koff + 16); }
+        if constexpr (AMODE == A_SWIGLU) {
+            // logical k0 = s*KS + q*(KS/4): 32-block = k0 >> 5, offset inside = k0 & 31; gate at 64*block + off, up 32 further
+            const int k0 = s * KS + q * (KS / 4);
+            const long long goff = ((long long)(k0 >> 5) * 64 + (k0 & 31)) * SZ;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) { a0[t] = ld16(arow[t] + koff); a1[t] = ld16(arow[t] + koff + 16); }
+            for (int t = 0; t < MT; ++t) {
+                r.a0[t] = ld16(arow[t] + goff); r.a1[t] = ld16(arow[t] + goff + 16);
+                r.x0[t] = ld16(arow[t] + goff + 32 * SZ); r.x1[t] = ld16(arow[t] + goff + 32 * SZ + 16);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { r.a0[t] = ld16(arow[t] + koff); r.a1[t] = ld16(arow[t] + koff + 16); }
+            if constexpr (AMODE == A_RMSNORM) { r.n0 = ld16(p.norm_w + koff); r.n1 = ld16(p.norm_w + koff + 16); }
+        }
+    };
+    auto consume = [&](StepRegs<NT, MT>& r) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (AMODE == A_RMSNORM) {
+                float f0[HN], f1[HN];
+#pragma unroll
+                for (int e = 0; e < HN; ++e) {
+                    const float x0 = elem<T>(r.a0[mt], e), x1 = elem<T>(r.a1[mt], e);
+                    ss[mt] += x0 * x0 + x1 * x1;
+                    f0[e] = x0 * elem<T>(r.n0, e);
+                    f1[e] = x1 * elem<T>(r.n1, e);
+                }
+                r.a0[mt] = pack<T>(f0); r.a1[mt] = pack<T>(f1);
+            } else if constexpr (AMODE == A_SWIGLU) {
+                float f0[HN], f1[HN];
+#pragma unroll
+                for (int e = 0; e < HN; ++e) {
+                    f0[e] = silu(elem<T>(r.a0[mt], e)) * elem<T>(r.x0[mt], e);
+                    f1[e] = silu(elem<T>(r.a1[mt], e)) * elem<T>(r.x1[mt], e);
+                }
+                r.a0[mt] = pack<T>(f0); r.a1[mt] = pack<T>(f1);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (SZ == 2) {
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[mt]), __builtin_bit_cast(bf16x8, w0[nt]), acc[nt][mt], 0, 0, 0);
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[mt]), __builtin_bit_cast(bf16x8, w1[nt]), acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r.a0[mt]), __builtin_bit_cast(bf16x8, r.w0[nt]), acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r.a1[mt]), __builtin_bit_cast(bf16x8, r.w1[nt]), acc[nt][mt], 0, 0, 0);
                 } else {
-                    const f32x4 x0 = __builtin_bit_cast(f32x4, a0[mt]), x1 = __builtin_bit_cast(f32x4, a1[mt]);
-                    const f32x4 y0 = __builtin_bit_cast(f32x4, w0[nt]), y1 = __builtin_bit_cast(f32x4, w1[nt]);
+                    const f32x4 x0 = __builtin_bit_cast(f32x4, r.a0[mt]), x1 = __builtin_bit_cast(f32x4, r.a1[mt]);
+                    const f32x4 y0 = __builtin_bit_cast(f32x4, r.w0[nt]), y1 = __builtin_bit_cast(f32x4, r.w1[nt]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], y0[j], acc[nt][mt], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], y1[j], acc[nt][mt], 0, 0, 0);
                 }
             }
+    };
+
+    // two steps of loads in flight per wave
+    int s = wave;
+    for (; s + 8 < nsteps; s += 16) {
+        StepRegs<NT, MT> r0, r1;
+        issue(s, r0);
+        issue(s + 8, r1);
+        consume(r0);
+        consume(r1);
+    }
+    if (s < nsteps) {
+        StepRegs<NT, MT> r0;
+        issue(s, r0);
+        consume(r0);
     }
 
     // ---- combine the 8 K-slices through LDS ----
@@ -89,8 +182,47 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<f32x4*>(red + ((((wave * NT + nt) * MT + mt) * 64 + lane) << 2)) = acc[nt][mt];
+    if constexpr (AMODE == A_RMSNORM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v = ss[mt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) red_ss[(wave * MT + mt) * 16 + c16] = v;
+        }
+    }
     __syncthreads();
     // C/D map of the 16x16 MFMA: col (n) = lane & 15, row (m) = 4 * (lane >> 4) + reg
+    if constexpr (NT == 4) {
+        if (p.swiglu_out) {
+            // tiles 0,1 = 32 gate rows, tiles 2,3 = the matching 32 up rows; C is [M, N/2]
+            for (int o = tid; o < 2 * MT * 256; o += 512) {
+                const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
+                const int mt = tile % MT, nt = tile / MT;        // nt in {0,1}
+                float g = 0.f, u = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    g += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
+                    u += red[((((w * NT + nt + 2) * MT + mt) * 64 + ln) << 2) + reg];
+                }
+                const int mrow = 4 * (ln >> 4) + reg;
+                const int m = mt * 16 + mrow;
+                const int n = n_base + nt * 16 + (ln & 15);       // gate row index inside W
+                if (n < p.N && m < p.M) {
+                    if constexpr (AMODE == A_RMSNORM) {
+                        float sq = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                        const float r = rsqrtf(sq / (float)p.K + p.norm_eps);
+                        g *= r; u *= r;
+                    }
+                    const int col = (n_base >> 1) + nt * 16 + (ln & 15);
+                    reinterpret_cast<T*>(p.C)[(long long)m * p.ldc + col] = from_f32<T>(silu(g) * u);
+                }
+            }
+            return;
+        }
+    }
     for (int o = tid; o < NT * MT * 256; o += 512) {
         const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
         const int mt = tile % MT, nt = tile / MT;
@@ -98,8 +230,15 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
         const int n = n_base + nt * 16 + (ln & 15);
-        const int m = mt * 16 + 4 * (ln >> 4) + reg;
+        const int mrow = 4 * (ln >> 4) + reg;
+        const int m = mt * 16 + mrow;
         if (n < p.N && m < p.M) {
+            if constexpr (AMODE == A_RMSNORM) {
+                float sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                v *= rsqrtf(sq / (float)p.K + p.norm_eps);
+            }
             if (p.bias) v += to_f32<T>(reinterpret_cast<const T*>(p.bias)[n]);
             if (p.res) v += to_f32<T>(reinterpret_cast<const T*>(p.res)[(long long)m * p.ldres + n]);
             if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)m * p.ldc + n] = v;
@@ -108,15 +247,24 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     }
 }
 
-template <typename T, int NT>
-void launch_mt(const SkinnyP& p, int mt, hipStream_t s) {
+template <typename T, int NT, int MT>
+void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
     const dim3 grid(cdiv(p.N, NT * 16)), block(512);
-    const size_t lds = (size_t)8 * NT * mt * 64 * 4 * sizeof(float);
+    const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
+    switch (amode) {
+        case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM>), grid, block, lds, s, p); break;
+        case A_SWIGLU: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_SWIGLU>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_PLAIN>), grid, block, lds, s, p); break;
+    }
+}
+
+template <typename T, int NT>
+void launch_mt(const SkinnyP& p, int mt, int amode, hipStream_t s) {
     switch (mt) {
-        case 1: hipLaunchKernelGGL((skinny_kernel<T, NT, 1>), grid, block, lds, s, p); break;
-        case 2: hipLaunchKernelGGL((skinny_kernel<T, NT, 2>), grid, block, lds, s, p); break;
-        case 3: hipLaunchKernelGGL((skinny_kernel<T, NT, 3>), grid, block, lds, s, p); break;
-        default: hipLaunchKernelGGL((skinny_kernel<T, NT, 4>), grid, block, lds, s, p); break;
+        case 1: launch_mode<T, NT, 1>(p, amode, s); break;
+        case 2: launch_mode<T, NT, 2>(p, amode, s); break;
+        case 3: launch_mode<T, NT, 3>(p, amode, s); break;
+        default: launch_mode<T, NT, 4>(p, amode, s); break;
     }
 }
 
@@ -130,25 +278,32 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     const int ks = a->dtype == AFHIP_BF16 ? 64 : 32;
     AFHIP_CHECK(a->K % ks == 0, "afhip_gemm_skinny: K=%d must be a multiple of %d", a->K, ks);
     AFHIP_CHECK(a->A && a->W && a->C, "afhip_gemm_skinny: null operand");
-    AFHIP_CHECK(a->act == AFHIP_ACT_NONE && a->conv_C == 0 && a->res_row_mod == 0, "afhip_gemm_skinny: act/conv/row-mod unsupported");
+    AFHIP_CHECK((a->act == AFHIP_ACT_NONE || a->act == AFHIP_ACT_SWIGLU) && a->conv_C == 0 && a->res_row_mod == 0, "afhip_gemm_skinny: act/conv/row-mod unsupported");
+    AFHIP_CHECK(!(a->a_norm_w && a->a_swiglu), "afhip_gemm_skinny: a_norm_w and a_swiglu are exclusive");
     const size_t sz = dtype_size(a->dtype);
     AFHIP_CHECK(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0 && (a->lda * sz) % 16 == 0 && (a->ldw * sz) % 16 == 0,
                 "afhip_gemm_skinny: A/W rows must be 16-byte aligned");
-    AFHIP_CHECK(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, "afhip_gemm_skinny: leading dimension too small");
+    const bool sw_out = a->act == AFHIP_ACT_SWIGLU;
+    AFHIP_CHECK(a->lda >= (a->a_swiglu ? 2 * a->K : a->K) && a->ldw >= a->K && a->ldc >= (sw_out ? a->N / 2 : a->N), "afhip_gemm_skinny: leading dimension too small");
     if (a->residual) AFHIP_CHECK(a->ldres >= a->N, "afhip_gemm_skinny: ldres < N");
+    if (a->a_norm_w) AFHIP_CHECK(((uintptr_t)a->a_norm_w % 16) == 0, "afhip_gemm_skinny: a_norm_w must be 16-byte aligned");
     SkinnyP p;
     p.A = (const char*)a->A; p.W = (const char*)a->W; p.bias = (const char*)a->bias; p.res = (const char*)a->residual;
+    p.norm_w = (const char*)a->a_norm_w; p.norm_eps = a->a_norm_eps;
     p.C = (char*)a->C;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldres = a->ldres;
     p.out_f32 = a->out_f32;
+    const int amode = a->a_norm_w ? A_RMSNORM : (a->a_swiglu ? A_SWIGLU : A_PLAIN);
     const int mt = cdiv(a->M, 16);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = a->N >= 8192 && mt <= 2;   // NT=4 needs 8*NT*MT KiB of LDS for the K-slice combine
+    if (sw_out) AFHIP_CHECK(wide && a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm_skinny: SWIGLU epilogue needs N >= 8192, N %% 64 == 0, M <= 32, no bias/residual");
+    p.swiglu_out = sw_out ? 1 : 0;
     if (a->dtype == AFHIP_BF16) {
-        if (wide) launch_mt<bf16, 4>(p, mt, s); else launch_mt<bf16, 1>(p, mt, s);
+        if (wide) launch_mt<bf16, 4>(p, mt, amode, s); else launch_mt<bf16, 1>(p, mt, amode, s);
     } else {
-        if (wide) launch_mt<float, 4>(p, mt, s); else launch_mt<float, 1>(p, mt, s);
+        if (wide) launch_mt<float, 4>(p, mt, amode, s); else launch_mt<float, 1>(p, mt, amode, s);
     }
     AFHIP_LAUNCH_CHECK();
     return 0;

@@ -40,7 +40,8 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
 }
 
 int gemm_any(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
-             int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s) {
+             int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s, const void* norm_w = nullptr,
+             float norm_eps = 0.f, int a_swiglu = 0) {
     afhip_gemm_args g;
     g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -48,7 +49,8 @@ int gemm_any(const void* A, const void* W, const void* bias, const void* res, vo
     g.dtype = dtype; g.act = act; g.res_row_mod = 0;
     g.conv_Tin = g.conv_Tout = g.conv_stride = g.conv_C = 0;
     g.out_f32 = out_f32;
-    if (M <= 64 && act == AFHIP_ACT_NONE) return afhip_gemm_skinny(&g, s);
+    g.a_norm_w = norm_w; g.a_norm_eps = norm_eps; g.a_swiglu = a_swiglu;
+    if (M <= 64 && (act == AFHIP_ACT_NONE || (act == AFHIP_ACT_SWIGLU && N >= 8192 && M <= 32))) return afhip_gemm_skinny(&g, s);
     return afhip_gemm(&g, s);
 }
 
@@ -77,18 +79,24 @@ __global__ void add_stream_emb_kernel(const T* __restrict__ hidden, const T* __r
     hs[i] = from_f32<T>(v);
 }
 
-// first-index argmax over the allowed intervals; one workgroup per row
-__global__ __launch_bounds__(1024) void masked_argmax_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ iv,
-                                                             int n_iv, int64_t* __restrict__ token) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    const int r = blockIdx.x, tid = threadIdx.x;
+// first-index argmax over the allowed intervals, two passes: AM_G workgroups per row scan interleaved 256-element
+// slices and leave (value, index) partials in a device scratch, one wave per row merges them (ties -> smaller index,
+// like torch.argmax).  Scratch is library-owned and sized for AM_MAXROWS rows; calls on different streams must not overlap.
+constexpr int AM_G = 64, AM_MAXROWS = 256;
+__device__ float g_am_val[AM_MAXROWS * AM_G];
+__device__ int g_am_idx[AM_MAXROWS * AM_G];
+
+__global__ __launch_bounds__(256) void masked_argmax_part_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ iv,
+                                                                 int n_iv) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (long long)r * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int k = 0; k < n_iv; ++k) {
         const int lo = iv[2 * k], hi = iv[2 * k + 1];
-        for (int i = lo + tid; i < hi; i += 1024) {
+        for (int i = lo + g * 256 + tid; i < hi; i += AM_G * 256) {
             const float v = row[i];
             if (v > best || (v == best && i < bi)) { best = v; bi = i; }
         }
@@ -102,12 +110,25 @@ __global__ __launch_bounds__(1024) void masked_argmax_kernel(const float* __rest
     if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        // an all -inf / NaN row falls back to the first allowed id, like argmax over a masked row picks index 0 of ties
-        if (bi == 0x7fffffff) bi = n_iv > 0 ? iv[0] : 0;
-        token[r] = bi;
+        g_am_val[r * AM_G + g] = best;
+        g_am_idx[r * AM_G + g] = bi;
     }
+}
+
+__global__ __launch_bounds__(64) void masked_argmax_final_kernel(const int32_t* __restrict__ iv, int n_iv, int64_t* __restrict__ token) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float best = g_am_val[r * AM_G + lane];
+    int bi = g_am_idx[r * AM_G + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    // an all -inf / NaN row falls back to the first allowed id
+    if (lane == 0) token[r] = (bi == 0x7fffffff) ? (n_iv > 0 ? iv[0] : 0) : bi;
 }
 
 // ids[b, 0] = prev[b]; ids[b, 1..S) = 0 (pad)      (prev_token layout of lm/parallel.py:479,540-541)
@@ -169,8 +190,13 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
     for (int l = 0; l < w->n_layers; ++l) {
         char* kc = (char*)cache->k + (size_t)l * layer_kv;
         char* vc = (char*)cache->v + (size_t)l * layer_kv;
-        if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
-        if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        const bool skinny = rows <= 64;       // decode: RMSNorm and SwiGLU are folded into the weight-streaming GEMMs
+        if (skinny) {
+            if ((rc = gemm_any(ws.x, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln1_w[l], w->rms_eps))) return rc;
+        } else {
+            if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
+            if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        }
         if ((rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
         afhip_attn_args a;
         a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
@@ -196,20 +222,25 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         }
         if ((rc = afhip_attention(&a, s))) return rc;
         if ((rc = gemm_any(ws.att, w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
-        if ((rc = afhip_rmsnorm(ws.x, w->ln2_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
-        const char* mlp_in;
-        if (rows <= 64) {
-            if ((rc = gemm_any(ws.nb, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, 2 * I, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
-            const long long n = (long long)rows * I;
-            if (dt == AFHIP_BF16) hipLaunchKernelGGL(swiglu_interleaved_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)ws.act, (bf16*)ws.act2, rows, I);
-            else hipLaunchKernelGGL(swiglu_interleaved_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws.act, (float*)ws.act2, rows, I);
-            AFHIP_LAUNCH_CHECK();
-            mlp_in = ws.act2;
+        if (skinny) {
+            const char* mlp_in = ws.act;
+            if (2 * I >= 8192 && rows <= 32) {
+                // gate/up GEMM with RMSNorm on its A load and SwiGLU as its epilogue -> [rows, I]
+                if ((rc = gemm_any(ws.x, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s, w->ln2_w[l], w->rms_eps))) return rc;
+            } else {
+                if ((rc = gemm_any(ws.x, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, 2 * I, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln2_w[l], w->rms_eps))) return rc;
+                const long long n = (long long)rows * I;
+                if (dt == AFHIP_BF16) hipLaunchKernelGGL(swiglu_interleaved_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)ws.act, (bf16*)ws.act2, rows, I);
+                else hipLaunchKernelGGL(swiglu_interleaved_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws.act, (float*)ws.act2, rows, I);
+                AFHIP_LAUNCH_CHECK();
+                mlp_in = ws.act2;
+            }
+            if ((rc = gemm_any(mlp_in, w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         } else {
+            if ((rc = afhip_rmsnorm(ws.x, w->ln2_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
             if ((rc = gemm_any(ws.nb, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s))) return rc;
-            mlp_in = ws.act;
+            if ((rc = gemm_any(ws.act, w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         }
-        if ((rc = gemm_any(mlp_in, w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
     }
     return afhip_rmsnorm(ws.x, w->norm_w, hidden_out, rows, H, w->rms_eps, dt, s);
 }
@@ -240,7 +271,9 @@ extern "C" int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int
 extern "C" int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
                                    void* stream) {
     AFHIP_CHECK(logits && allowed && token && rows > 0 && n_iv > 0 && ld > 0, "afhip_masked_argmax: bad args");
-    hipLaunchKernelGGL(masked_argmax_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ld, allowed, n_iv, token);
+    AFHIP_CHECK(rows <= AM_MAXROWS, "afhip_masked_argmax: rows=%d exceeds %d", rows, AM_MAXROWS);
+    hipLaunchKernelGGL(masked_argmax_part_kernel, dim3(AM_G, rows), dim3(256), 0, (hipStream_t)stream, logits, ld, allowed, n_iv);
+    hipLaunchKernelGGL(masked_argmax_final_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, allowed, n_iv, token);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -78,6 +78,10 @@ typedef struct {
     int res_row_mod;
     int conv_Tin, conv_Tout, conv_stride, conv_C;
     int out_f32; /* store C as f32 whatever `dtype` is (logits) */
+    /* afhip_gemm_skinny only: producer ops folded into the A-operand load (decode path) */
+    const void* a_norm_w; /* != NULL: A' = RMSNorm(A) with this gain [K] (modeling_qwen2.py:238-252) */
+    float a_norm_eps;
+    int a_swiglu;         /* != 0: A is the 32-row interleaved gate/up buffer [M, 2K], A' = silu(gate)*up */
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 

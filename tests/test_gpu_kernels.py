@@ -334,3 +334,65 @@ def test_attention_decode_split_context(dt, nq, nkv, hd, tk):
     _check(out, ref.reshape(B, nq * hd), *_tol(dt, (2e-5, 1e-4), (2e-2, 2e-2)), f"decode attention tk={tk}")
     out2 = ops.attention_decode(qd, kd, vd, nq, nkv, tk, key_split=64)
     _check(out2, ref.reshape(B, nq * hd), *_tol(dt, (2e-5, 1e-4), (2e-2, 2e-2)), f"decode attention tk={tk} split 64")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M", [1, 8, 33])
+def test_gemm_skinny_fused_rmsnorm_and_swiglu(dt, M):
+    """decode GEMMs with the producer op folded into the A load: RMSNorm in front of q/k/v and gate/up, SwiGLU in front of down"""
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    H, I, N = 768, 1024, 9000
+    xd, xf = _q(_rand(M, H, seed=71) * 3.0, dt)
+    gd, gf = _q(1 + 0.1 * _rand(H, seed=72), dt)
+    wd, wf = _q(_rand(N, H, seed=73, scale=0.05), dt)
+    bd, bf = _q(_rand(N, seed=74, scale=0.1), dt)
+    out = torch.empty(M, N, dtype=dt, device=_dev())
+    g = L.GemmArgs()
+    g.A, g.W, g.bias, g.C = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, N, H, H, H, N
+    g.dtype, g.a_norm_w, g.a_norm_eps = L.dtype_code(dt), gd.data_ptr(), 1e-6
+    L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+    var = xf.pow(2).mean(-1, keepdim=True)
+    ref = (gf * (xf * torch.rsqrt(var + 1e-6))) @ wf.T + bf
+    _check(out, ref, *_tol(dt, (5e-5, 5e-5), (4e-2, 3e-2)), f"skinny+rmsnorm M={M}")
+    # SwiGLU-fused down projection from the interleaved gate/up buffer
+    gate = _rand(M, I, seed=75).to(dt)
+    up = _rand(M, I, seed=76).to(dt)
+    inter = torch.stack([gate.view(M, I // 32, 32), up.view(M, I // 32, 32)], dim=2).reshape(M, 2 * I).contiguous().to(_dev())
+    w2d, w2f = _q(_rand(H, I, seed=77, scale=0.05), dt)
+    rd, rf = _q(_rand(M, H, seed=78), dt)
+    out2 = torch.empty(M, H, dtype=dt, device=_dev())
+    g2 = L.GemmArgs()
+    g2.A, g2.W, g2.residual, g2.C = inter.data_ptr(), w2d.data_ptr(), rd.data_ptr(), out2.data_ptr()
+    g2.M, g2.N, g2.K, g2.lda, g2.ldw, g2.ldc, g2.ldres = M, H, I, 2 * I, I, H, H
+    g2.dtype, g2.a_swiglu = L.dtype_code(dt), 1
+    L.check(lib.afhip_gemm_skinny(C.byref(g2), L.stream_ptr()))
+    act = (F.silu(gate.float()) * up.float()).to(dt).float()
+    _check(out2, act @ w2f.T + rf, *_tol(dt, (5e-5, 5e-5), (3e-2, 3e-2)), f"skinny+swiglu M={M}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M", [1, 8, 32])
+def test_gemm_skinny_rmsnorm_load_swiglu_epilogue(dt, M):
+    """decode gate/up GEMM: RMSNorm folded into the A load, SwiGLU as the K-slice-combine epilogue -> [M, I]"""
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    H, I = 768, 4096
+    xd, xf = _q(_rand(M, H, seed=81) * 2.0, dt)
+    gd, gf = _q(1 + 0.1 * _rand(H, seed=82), dt)
+    gate = _rand(I, H, seed=83, scale=0.05).to(dt)
+    up = _rand(I, H, seed=84, scale=0.05).to(dt)
+    packed = torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous().to(_dev())
+    out = torch.empty(M, I, dtype=dt, device=_dev())
+    g = L.GemmArgs()
+    g.A, g.W, g.C = xd.data_ptr(), packed.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, 2 * I, H, H, H, I
+    g.dtype, g.act, g.a_norm_w, g.a_norm_eps = L.dtype_code(dt), L.ACT_SWIGLU, gd.data_ptr(), 1e-6
+    L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+    var = xf.pow(2).mean(-1, keepdim=True)
+    h = gf * (xf * torch.rsqrt(var + 1e-6))
+    ref = F.silu(h @ gate.float().T) * (h @ up.float().T)
+    _check(out, ref, *_tol(dt, (5e-5, 5e-5), (4e-2, 3e-2)), f"skinny rmsnorm+swiglu M={M}")
