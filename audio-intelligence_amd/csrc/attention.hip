@@ -27,7 +27,8 @@ struct AttnP {
     long long q_hs, kv_hs, o_hs;
     int causal, q_pos0;
     float scale_log2;
-    int key_split;          // > 0: blockIdx.x enumerates key ranges of this many keys (Tq <= 32), partials go to part_o / part_ml
+    int n_xt;               // x-tiles per (batch, head): query tiles, or key ranges when key_split > 0
+    int key_split;          // > 0: the x-tile index enumerates key ranges of this many keys (Tq <= 32), partials go to part_o / part_ml
     float* part_o;          // [split][B][n_q][32][HD] unnormalised O^T columns
     float* part_ml;         // [split][B][n_q][32][2]  running max (raw score units) and sum
 };
@@ -67,10 +68,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const int b = blockIdx.z, hq = blockIdx.y;
+    // 1-D grid over (x-tile, head, batch).  Workgroups id and id+8 share an XCD (round-robin dispatch), so with
+    // id = xcd + 8 * (xtile + n_xt * head_group), head = 8 * head_group + xcd, the x-tiles (query tiles or key ranges) of one
+    // (batch, head) run back to back on ONE XCD and its K/V is fetched from HBM once, not once per query tile
+    // (FETCH_SIZE was 2.1 GB per launch for 0.37 GB of q/k/v).  Falls back to head-major order when heads*batch % 8 != 0.
+    const int nh = p.n_q * p.B;
+    int xt, hb;
+    if ((nh & 7) == 0) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        xt = r % p.n_xt;
+        hb = (r / p.n_xt) * 8 + xcd;
+    } else {
+        xt = blockIdx.x % p.n_xt;
+        hb = blockIdx.x / p.n_xt;
+    }
+    const int b = hb / p.n_q, hq = hb % p.n_q;
     const int hkv = hq / (p.n_q / p.n_kv);
-    const int split = p.key_split > 0 ? blockIdx.x : 0;
-    const int q0 = p.key_split > 0 ? 0 : blockIdx.x * QT;
+    const int split = p.key_split > 0 ? xt : 0;
+    const int q0 = p.key_split > 0 ? 0 : xt * QT;
     const int qrow = q0 + wave * 32 + fr;                 // this lane's query
     const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
     const int qpos = p.q_pos0 + qrow;
@@ -350,7 +365,6 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
                 "afhip_attention: strides must keep 16-byte alignment");
     AFHIP_CHECK(a->ld_o >= a->hd, "afhip_attention: ld_o too small");
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
-    AFHIP_CHECK(a->n_q <= 65535 && a->B <= 65535, "afhip_attention: grid too large");
 
     AttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;
@@ -376,7 +390,9 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         p.part_o = (float*)a->partial_ws;
         p.part_ml = p.part_o + (size_t)n_split * a->B * a->n_q * 32 * a->hd;
     }
-    const dim3 grid(a->key_split > 0 ? n_split : cdiv(a->Tq, QT), a->n_q, a->B), block(256);
+    p.n_xt = a->key_split > 0 ? n_split : cdiv(a->Tq, QT);
+    AFHIP_CHECK((long long)p.n_xt * a->n_q * a->B < (1ll << 31), "afhip_attention: grid too large");
+    const dim3 grid((unsigned)(p.n_xt * a->n_q * a->B)), block(256);
     static int nbuf = -1;
     if (nbuf < 0) { const char* e = getenv("AFHIP_ATTN_NBUF"); nbuf = (e && e[0] == '1') ? 1 : 2; }   // A/B switch
     const size_t lds = (size_t)nbuf * 2 * KT * a->hd * sz;     // stages of (K tile + V tile)

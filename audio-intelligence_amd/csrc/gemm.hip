@@ -31,6 +31,7 @@ struct GemmP {
     int conv_Tin, conv_Tout, conv_stride, conv_C;
     int tiles_m, tiles_n;
     int out_f32;
+    int group_m;   // tile rasterisation: consecutive workgroups walk group_m M-tiles before the next N-tile
     int vec;   // 4-element vector epilogue allowed (alignment / range checked on the host)
 };
 
@@ -287,7 +288,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
+    // grouped rasterisation: the 32 workgroups an XCD runs at a time cover ~group_m M-tiles x (32 / group_m) N-tiles, so
+    // both the activation panels and the weight panels are shared through that XCD's 4-MiB L2 (with plain row-major order
+    // every M-tile re-fetched all weight panels from beyond L2: FETCH_SIZE was 6.5x the algorithmic bytes)
+    const int width = p.group_m * p.tiles_n;
+    const int grp = wg / width, first_m = grp * p.group_m;
+    const int gsize = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
+    const int tm = first_m + (wg % width) % gsize, tn = (wg % width) / gsize;
     const int m0 = tm * BM2, n0 = tn * BN2;
 
     // ---- DMA coordinates: pass i of wave w fills rows (i*8 + w)*8 .. +8 of a tile; lane -> (row, slot) ----
@@ -563,6 +570,12 @@ static bool force_small_tile() {
     return v == 1;
 }
 
+static int gemm_group_m() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AFHIP_GEMM_GROUP_M"); v = e ? atoi(e) : 4; if (v < 1) v = 1; }
+    return v;
+}
+
 static bool use_mfma16() {
     // A/B switch: the 16x16x32 body measured within +-3 % of the 32x32x16 one on MI355X (tools/gemm_bench.py), so the
     // 32x32 body (shared with the f32 path) stays the default
@@ -642,6 +655,7 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     p.act = a->act; p.res_row_mod = a->res_row_mod;
     p.conv_Tin = a->conv_Tin; p.conv_Tout = a->conv_Tout; p.conv_stride = a->conv_stride; p.conv_C = a->conv_C;
     p.out_f32 = a->out_f32;
+    p.group_m = gemm_group_m();
     {
         const size_t osz = a->out_f32 ? 4 : sz;
         const bool al = ((uintptr_t)a->C % (4 * osz)) == 0 && (a->ldc % 4) == 0 &&

@@ -188,3 +188,26 @@ def test_full_shape_encoder_against_reference_golden(dtype, tol_max, tol_mean):
         got = out[b].float().cpu().numpy()[fc.sample_row_index(750)]
         err = np.abs(got - arr["enc_full_s30_final"])
         assert err.max() <= tol_max and err.mean() <= tol_mean, (dtype, float(err.max()), float(err.mean()))
+
+
+def test_long_audio_window_path_single_gpu():
+    """Long-audio entry (config 4) on one GPU: 75-s clip -> three 30-s windows (the last one 15 s, zero-padded and masked
+    through its sample count) -> tokens; must equal the oracle's SoundTower on the same windows."""
+    _need_gpu()
+    from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+    from audio_intelligence_amd.long_audio import split_windows, encode_windows_sharded, make_tower_encode_fn
+    cfg, sd = H.tiny_enc()
+    io = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="float32", device=DEV, encoder=_tiny_encoder())
+    clip = fc.make_wav(4242, 75 * 16000)
+    spans = split_windows(len(clip))
+    assert spans == [(0, 480000), (480000, 960000), (960000, 1200000)]
+    wins = np.zeros((3, 480000), np.float32)
+    for i, (a, b) in enumerate(spans):
+        wins[i, : b - a] = clip[a:b]
+    n_valid = torch.tensor([b - a for a, b in spans])
+    out = encode_windows_sharded(make_tower_encode_fn(io), torch.from_numpy(wins).to(DEV), n_valid.to(DEV))
+    assert list(out.shape) == [3, 750, 384]
+    mel = torch.from_numpy(oracle.logmel.log_mel(wins))                      # [3,128,3000]
+    mask = (torch.arange(3000)[None, :] < (n_valid // 160)[:, None]).long()[:, None, :]
+    ref = oracle.afwhisper.sound_tower(mel, mask, sd, cfg)
+    assert _maxerr(out, ref) <= 3e-4
