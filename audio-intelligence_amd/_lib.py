@@ -25,7 +25,8 @@ class GemmArgs(C.Structure):
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldres", C.c_int),
                 ("dtype", C.c_int), ("act", C.c_int), ("res_row_mod", C.c_int),
                 ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int),
-                ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int)]
+                ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
+                ("w_scale", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -56,7 +57,10 @@ class LlmWeights(C.Structure):
                 ("ln1_w", c_void_pp), ("qkv_w", c_void_pp), ("qkv_b", c_void_pp), ("o_w", c_void_pp),
                 ("ln2_w", c_void_pp), ("gu_w", c_void_pp), ("down_w", c_void_pp),
                 ("norm_w", C.c_void_p), ("lm_head", C.c_void_p), ("stream_emb", C.c_void_p),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int),
+                ("qkv_w8", c_void_pp), ("qkv_s", c_void_pp), ("o_w8", c_void_pp), ("o_s", c_void_pp),
+                ("gu_w8", c_void_pp), ("gu_s", c_void_pp), ("down_w8", c_void_pp), ("down_s", c_void_pp),
+                ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p)]
 
 
 class KvCache(C.Structure):

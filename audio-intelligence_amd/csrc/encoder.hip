@@ -46,7 +46,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
     g.dtype = dtype; g.act = act; g.res_row_mod = row_mod;
     g.conv_Tin = cTin; g.conv_Tout = cTout; g.conv_stride = cStride; g.conv_C = cC;
     g.out_f32 = 0;
-    g.a_norm_w = nullptr; g.a_norm_eps = 0.f; g.a_swiglu = 0;
+    g.a_norm_w = nullptr; g.a_norm_eps = 0.f; g.a_swiglu = 0; g.w_scale = nullptr;
     return afhip_gemm(&g, s);
 }
 

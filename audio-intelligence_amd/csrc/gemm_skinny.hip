@@ -270,8 +270,11 @@ void launch_mt(const SkinnyP& p, int mt, int amode, hipStream_t s) {
 
 }  // namespace
 
+int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream);   // gemm_skinny_fp8.hip
+
 extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_gemm_skinny: null args");
+    if (a->w_scale != nullptr) return afhip_gemm_skinny_fp8_impl(a, stream);
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_gemm_skinny: bad dtype %d", a->dtype);
     AFHIP_CHECK(a->M > 0 && a->M <= 64, "afhip_gemm_skinny: M=%d must be in [1,64] (use afhip_gemm)", a->M);
     AFHIP_CHECK(a->N > 0 && a->K > 0, "afhip_gemm_skinny: bad shape N=%d K=%d", a->N, a->K);

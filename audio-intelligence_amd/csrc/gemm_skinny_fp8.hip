@@ -1,0 +1,254 @@
+// Decode GEMM with FP8 (OCP e4m3) weights and bf16 activations (W8A16): C[M,N] = A'[M,K] . (s_n * Wq[N,K])^T.
+// The decode step is bound by the bytes of W it must stream (gemm_skinny.hip); storing W as e4m3 with one f32 scale per
+// output row halves them.  Same structure as the bf16 kernel -- weights straight from HBM into registers, 8 waves
+// interleaved over K steps, LDS combine -- with a K step of 128 so a lane still reads 32 contiguous bytes of its weight
+// row (4 lanes = one 128-byte line); the 32 weights are widened to bf16 in registers (v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32)
+// and fed to four v_mfma_f32_16x16x32_bf16 against the lane's 32 activations.  The row scale is applied to the f32
+// accumulator in the epilogue, next to the fused RMSNorm row scale / SwiGLU epilogue of the bf16 kernel.
+// Reference counterpart: none (BASELINE config 5 "fp8 MFMA GEMMs"); checked against the dequantised weights in f32.
+#include "common.h"
+
+namespace {
+
+enum { A_PLAIN = 0, A_RMSNORM = 1 };
+
+struct SkinnyF8P {
+    const char* A;
+    const char* W;        // e4m3 bytes [N, ldw]
+    const float* wscale;  // [N]
+    const char* bias;
+    const char* res;
+    const char* norm_w;
+    char* C;
+    int M, N, K;
+    long long lda, ldw, ldc, ldres;
+    int out_f32;
+    float norm_eps;
+    int swiglu_out;
+};
+
+constexpr int KS8 = 128;
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// 4 fp8 bytes -> 4 bf16 packed in two dwords: v_cvt_scalef32_pk_bf16_fp8 widens two e4m3 values per instruction (exact)
+__device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t v, uint32_t& lo, uint32_t& hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)v, 1.0f, false);
+    const bf16x2_t p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)v, 1.0f, true);
+    lo = __builtin_bit_cast(uint32_t, p0);
+    hi = __builtin_bit_cast(uint32_t, p1);
+}
+
+template <int NT, int MT> struct StepRegs8 { u32x4 w[NT][2]; u32x4 a[MT][4]; u32x4 n[4]; };
+
+template <int NT, int MT, int AMODE>
+__global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NT][MT][64 lanes][4]
+    float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int n_base = blockIdx.x * (NT * 16);
+
+    const char* wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int n = n_base + t * 16 + c16;
+        n = n < p.N ? n : p.N - 1;
+        wrow[t] = p.W + (long long)n * p.ldw;
+    }
+    const char* arow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = t * 16 + c16;
+        m = m < p.M ? m : p.M - 1;
+        arow[t] = p.A + (long long)m * p.lda * 2;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) ss[b] = 0.f;
+
+    const int nsteps = p.K / KS8;
+    auto issue = [&](int s, StepRegs8<NT, MT>& r) {
+        const long long k0 = (long long)s * KS8 + q * 32;          // first of this lane's 32 K elements
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { r.w[t][0] = ld16(wrow[t] + k0); r.w[t][1] = ld16(wrow[t] + k0 + 16); }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r.a[t][c] = ld16(arow[t] + k0 * 2 + c * 16);
+        if constexpr (AMODE == A_RMSNORM) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r.n[c] = ld16(p.norm_w + k0 * 2 + c * 16);
+        }
+    };
+    auto consume = [&](StepRegs8<NT, MT>& r) {
+        if constexpr (AMODE == A_RMSNORM) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float x0 = bf16_lo(r.a[mt][c][d]), x1 = bf16_hi(r.a[mt][c][d]);
+                        ss[mt] += x0 * x0 + x1 * x1;
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        bf16x2_t pr;
+                        pr[0] = (bf16)(x0 * bf16_lo(r.n[c][d]));
+                        pr[1] = (bf16)(x1 * bf16_hi(r.n[c][d]));
+                        o[d] = __builtin_bit_cast(uint32_t, pr);
+                    }
+                    r.a[mt][c] = o;
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // widen this tile's 32 fp8 weights: dword d of half h holds k = 16 h + 4 d .. +4 -> bf16 chunk c = 2 h + (d >> 1)
+            u32x4 wb[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t lo, hi;
+                    fp8x4_to_bf16x4(r.w[nt][h][d], lo, hi);
+                    wb[2 * h + (d >> 1)][2 * (d & 1)] = lo;
+                    wb[2 * h + (d >> 1)][2 * (d & 1) + 1] = hi;
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r.a[mt][c]), __builtin_bit_cast(bf16x8, wb[c]), acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+    int s = wave;
+    for (; s + 8 < nsteps; s += 16) {
+        StepRegs8<NT, MT> r0, r1;
+        issue(s, r0);
+        issue(s + 8, r1);
+        consume(r0);
+        consume(r1);
+    }
+    if (s < nsteps) {
+        StepRegs8<NT, MT> r0;
+        issue(s, r0);
+        consume(r0);
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(red + ((((wave * NT + nt) * MT + mt) * 64 + lane) << 2)) = acc[nt][mt];
+    if constexpr (AMODE == A_RMSNORM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v = ss[mt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) red_ss[(wave * MT + mt) * 16 + c16] = v;
+        }
+    }
+    __syncthreads();
+    auto row_scale = [&](int mt, int mrow) {
+        if constexpr (AMODE == A_RMSNORM) {
+            float sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+            return rsqrtf(sq / (float)p.K + p.norm_eps);
+        } else {
+            return 1.0f;
+        }
+    };
+    if constexpr (NT == 4) {
+        if (p.swiglu_out) {
+            for (int o = tid; o < 2 * MT * 256; o += 512) {
+                const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
+                const int mt = tile % MT, nt = tile / MT;
+                float g = 0.f, u = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    g += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
+                    u += red[((((w * NT + nt + 2) * MT + mt) * 64 + ln) << 2) + reg];
+                }
+                const int mrow = 4 * (ln >> 4) + reg, m = mt * 16 + mrow;
+                const int n = n_base + nt * 16 + (ln & 15);
+                if (n + 32 < p.N + 1 && m < p.M) {
+                    const float r = row_scale(mt, mrow);
+                    g *= r * p.wscale[n];
+                    u *= r * p.wscale[n + 32];
+                    reinterpret_cast<bf16*>(p.C)[(long long)m * p.ldc + (n_base >> 1) + nt * 16 + (ln & 15)] = (bf16)(silu(g) * u);
+                }
+            }
+            return;
+        }
+    }
+    for (int o = tid; o < NT * MT * 256; o += 512) {
+        const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
+        const int mt = tile % MT, nt = tile / MT;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
+        const int n = n_base + nt * 16 + (ln & 15);
+        const int mrow = 4 * (ln >> 4) + reg, m = mt * 16 + mrow;
+        if (n < p.N && m < p.M) {
+            v *= row_scale(mt, mrow) * p.wscale[n];
+            if (p.bias) v += (float)reinterpret_cast<const bf16*>(p.bias)[n];
+            if (p.res) v += (float)reinterpret_cast<const bf16*>(p.res)[(long long)m * p.ldres + n];
+            if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)m * p.ldc + n] = v;
+            else reinterpret_cast<bf16*>(p.C)[(long long)m * p.ldc + n] = (bf16)v;
+        }
+    }
+}
+
+template <int NT, int MT>
+void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
+    const dim3 grid(cdiv(p.N, NT * 16)), block(512);
+    const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
+    if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_RMSNORM>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_PLAIN>), grid, block, lds, s, p);
+}
+
+template <int NT>
+void launch_mt8(const SkinnyF8P& p, int mt, int amode, hipStream_t s) {
+    if (mt == 1) launch_mode8<NT, 1>(p, amode, s);
+    else launch_mode8<NT, 2>(p, amode, s);
+}
+
+}  // namespace
+
+int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
+    AFHIP_CHECK(a->dtype == AFHIP_BF16, "afhip_gemm_skinny: fp8 weights need bf16 activations");
+    AFHIP_CHECK(a->M > 0 && a->M <= 32, "afhip_gemm_skinny(fp8): M=%d must be in [1,32]", a->M);
+    AFHIP_CHECK(a->K % KS8 == 0, "afhip_gemm_skinny(fp8): K=%d must be a multiple of %d", a->K, KS8);
+    AFHIP_CHECK(a->w_scale != nullptr && !a->a_swiglu, "afhip_gemm_skinny(fp8): w_scale missing / a_swiglu unsupported");
+    AFHIP_CHECK(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0 && (a->lda * 2) % 16 == 0 && a->ldw % 16 == 0,
+                "afhip_gemm_skinny(fp8): A/W rows must be 16-byte aligned");
+    const bool sw_out = a->act == AFHIP_ACT_SWIGLU;
+    AFHIP_CHECK(a->lda >= a->K && a->ldw >= a->K && a->ldc >= (sw_out ? a->N / 2 : a->N), "afhip_gemm_skinny(fp8): leading dimension too small");
+    SkinnyF8P p;
+    p.A = (const char*)a->A; p.W = (const char*)a->W; p.wscale = a->w_scale; p.bias = (const char*)a->bias;
+    p.res = (const char*)a->residual; p.norm_w = (const char*)a->a_norm_w; p.norm_eps = a->a_norm_eps;
+    p.C = (char*)a->C;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldres = a->ldres;
+    p.out_f32 = a->out_f32;
+    const int mt = cdiv(a->M, 16);
+    const bool wide = a->N >= 8192;
+    if (sw_out) AFHIP_CHECK(wide && a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm_skinny(fp8): SWIGLU epilogue needs N >= 8192, N %% 64 == 0, no bias/residual");
+    p.swiglu_out = sw_out ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int amode = a->a_norm_w ? A_RMSNORM : A_PLAIN;
+    if (wide) launch_mt8<4>(p, mt, amode, s); else launch_mt8<1>(p, mt, amode, s);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -41,7 +41,7 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
 
 int gemm_any(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
              int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s, const void* norm_w = nullptr,
-             float norm_eps = 0.f, int a_swiglu = 0) {
+             float norm_eps = 0.f, int a_swiglu = 0, const float* w_scale = nullptr) {
     afhip_gemm_args g;
     g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -49,7 +49,7 @@ int gemm_any(const void* A, const void* W, const void* bias, const void* res, vo
     g.dtype = dtype; g.act = act; g.res_row_mod = 0;
     g.conv_Tin = g.conv_Tout = g.conv_stride = g.conv_C = 0;
     g.out_f32 = out_f32;
-    g.a_norm_w = norm_w; g.a_norm_eps = norm_eps; g.a_swiglu = a_swiglu;
+    g.a_norm_w = norm_w; g.a_norm_eps = norm_eps; g.a_swiglu = a_swiglu; g.w_scale = w_scale;
     if (M <= 64 && (act == AFHIP_ACT_NONE || (act == AFHIP_ACT_SWIGLU && N >= 8192 && M <= 32))) return afhip_gemm_skinny(&g, s);
     return afhip_gemm(&g, s);
 }
@@ -191,8 +191,9 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         char* kc = (char*)cache->k + (size_t)l * layer_kv;
         char* vc = (char*)cache->v + (size_t)l * layer_kv;
         const bool skinny = rows <= 64;       // decode: RMSNorm and SwiGLU are folded into the weight-streaming GEMMs
+        const bool f8 = skinny && rows <= 32 && dt == AFHIP_BF16 && w->qkv_w8 != nullptr;   // W8A16 copies of the streamed weights
         if (skinny) {
-            if ((rc = gemm_any(ws.x, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln1_w[l], w->rms_eps))) return rc;
+            if ((rc = gemm_any(ws.x, f8 ? w->qkv_w8[l] : w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln1_w[l], w->rms_eps, 0, f8 ? w->qkv_s[l] : nullptr))) return rc;
         } else {
             if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
             if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
@@ -221,21 +222,21 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
             a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         }
         if ((rc = afhip_attention(&a, s))) return rc;
-        if ((rc = gemm_any(ws.att, w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if ((rc = gemm_any(ws.att, f8 ? w->o_w8[l] : w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s, nullptr, 0.f, 0, f8 ? w->o_s[l] : nullptr))) return rc;
         if (skinny) {
             const char* mlp_in = ws.act;
             if (2 * I >= 8192 && rows <= 32) {
                 // gate/up GEMM with RMSNorm on its A load and SwiGLU as its epilogue -> [rows, I]
-                if ((rc = gemm_any(ws.x, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s, w->ln2_w[l], w->rms_eps))) return rc;
+                if ((rc = gemm_any(ws.x, f8 ? w->gu_w8[l] : w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s, w->ln2_w[l], w->rms_eps, 0, f8 ? w->gu_s[l] : nullptr))) return rc;
             } else {
-                if ((rc = gemm_any(ws.x, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, 2 * I, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln2_w[l], w->rms_eps))) return rc;
+                if ((rc = gemm_any(ws.x, f8 ? w->gu_w8[l] : w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, 2 * I, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln2_w[l], w->rms_eps, 0, f8 ? w->gu_s[l] : nullptr))) return rc;
                 const long long n = (long long)rows * I;
                 if (dt == AFHIP_BF16) hipLaunchKernelGGL(swiglu_interleaved_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)ws.act, (bf16*)ws.act2, rows, I);
                 else hipLaunchKernelGGL(swiglu_interleaved_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws.act, (float*)ws.act2, rows, I);
                 AFHIP_LAUNCH_CHECK();
                 mlp_in = ws.act2;
             }
-            if ((rc = gemm_any(mlp_in, w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            if ((rc = gemm_any(mlp_in, f8 ? w->down_w8[l] : w->down_w[l], nullptr, ws.x, ws.x, rows, H, I, I, H, H, dt, AFHIP_ACT_NONE, 0, s, nullptr, 0.f, 0, f8 ? w->down_s[l] : nullptr))) return rc;
         } else {
             if ((rc = afhip_rmsnorm(ws.x, w->ln2_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
             if ((rc = gemm_any(ws.nb, w->gu_w[l], nullptr, nullptr, ws.act, rows, 2 * I, H, H, I, 0, dt, AFHIP_ACT_SWIGLU, 0, s))) return rc;
@@ -265,7 +266,9 @@ extern "C" int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int
         AFHIP_LAUNCH_CHECK();
         a = workspace;
     }
-    return gemm_any(a, w->lm_head, nullptr, nullptr, logits, rows * n_s, w->vocab, H, H, w->vocab, 0, dt, AFHIP_ACT_NONE, 1, s);
+    const bool f8 = rows * n_s <= 32 && dt == AFHIP_BF16 && w->lm_head8 != nullptr;
+    return gemm_any(a, f8 ? w->lm_head8 : w->lm_head, nullptr, nullptr, logits, rows * n_s, w->vocab, H, H, w->vocab, 0, dt, AFHIP_ACT_NONE, 1, s,
+                    nullptr, 0.f, 0, f8 ? w->lm_head_s : nullptr);
 }
 
 extern "C" int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,

@@ -131,6 +131,25 @@ class ParallelLLM(nn.Module):
         self._packed = None
         self._ws = None
         self._allowed = {}
+        self._fp8_decode = False
+
+    def enable_fp8_decode(self, on: bool = True):
+        """W8A16 decode (BASELINE config 5): keep an OCP-e4m3 copy (+ one f32 scale per output row) of every weight the
+        decode step streams -- q/k/v, o, gate/up, down, lm_head -- and let the skinny GEMMs read those (half the HBM bytes
+        per token).  Prefill keeps the bf16 weights.  bf16 models only."""
+        if on and self.dtype != torch.bfloat16:
+            raise L.AfhipError("fp8 decode weights need a bfloat16 model")
+        self._fp8_decode = bool(on)
+        self._packed = None
+        return self
+
+    @staticmethod
+    def _quantize_rows_e4m3(w: torch.Tensor):
+        """[N,K] -> (e4m3 bytes [N,K] as uint8, f32 scale [N]) with w ~= scale[n] * q[n,k]; 448 = e4m3 max."""
+        amax = w.float().abs().amax(dim=1).clamp_min(1e-12)
+        scale = (amax / 448.0).contiguous()
+        q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
+        return q.view(torch.uint8).contiguous(), scale
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -236,6 +255,18 @@ class ParallelLLM(nn.Module):
         for n in names:
             arrays[n] = L.ptr_array(lists[n])
             setattr(w, n, C.cast(arrays[n], L.c_void_pp))
+        if self._fp8_decode:
+            for src, dst_w, dst_s in (("qkv_w", "qkv_w8", "qkv_s"), ("o_w", "o_w8", "o_s"), ("gu_w", "gu_w8", "gu_s"), ("down_w", "down_w8", "down_s")):
+                qs, ss = [], []
+                for t in lists[src]:
+                    q8, sc = self._quantize_rows_e4m3(t)
+                    qs.append(P(q8))
+                    ss.append(P(sc))
+                arrays[dst_w], arrays[dst_s] = L.ptr_array(qs), L.ptr_array(ss)
+                setattr(w, dst_w, C.cast(arrays[dst_w], L.c_void_pp))
+                setattr(w, dst_s, C.cast(arrays[dst_s], L.c_void_pp))
+            q8, sc = self._quantize_rows_e4m3(self.lm_head.weight.detach())
+            w.lm_head8, w.lm_head_s = P(q8).data_ptr(), P(sc).data_ptr()
         w.norm_w = P(self.model.norm.weight).data_ptr()
         w.lm_head = P(self.lm_head.weight).data_ptr()
         w.stream_emb = P(self.stream_emb.weight).data_ptr()

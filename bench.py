@@ -142,7 +142,7 @@ def decode_leg(device, enc, fe, B, n_steps, warm):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     emb = model._embed(ids, batch)
-    hid, cache = model._forward_hidden(emb, model.new_cache(B, T + n_steps + warm + 8))
+    hid, cache = model._forward_hidden(emb, model.new_cache(B, T + 2 * (n_steps + warm) + 8))
     torch.cuda.synchronize()
     t_prefill = time.perf_counter() - t0
     tok = model.text_token.expand(B, -1, -1).clone()
@@ -154,17 +154,30 @@ def decode_leg(device, enc, fe, B, n_steps, warm):
     dt = time.perf_counter() - t0
     H, I, nl = LLM_7B["hidden_size"], LLM_7B["intermediate_size"], LLM_7B["num_hidden_layers"]
     kvw = LLM_7B["num_key_value_heads"] * (H // LLM_7B["num_attention_heads"])
-    w_bytes = nl * 2 * (H * H * 2 + 2 * H * kvw + 3 * H * I) + 2 * len(vocab) * H
-    ctx = T + warm + n_steps // 2
-    step_bytes = w_bytes + B * ctx * nl * 2 * kvw * 2
-    gbs = step_bytes * n_steps / dt / 1e9
+    w_elems = nl * (H * H * 2 + 2 * H * kvw + 3 * H * I) + len(vocab) * H
+
+    def leg(label, dt_s, wbytes):
+        ctx = cache.length - n_steps // 2
+        step_bytes = w_elems * wbytes + B * ctx * nl * 2 * kvw * 2
+        gbs = step_bytes * n_steps / dt_s / 1e9
+        return {"weights": label, "tokens_per_s": B * n_steps / dt_s, "ms_per_step": dt_s / n_steps * 1e3,
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                             "traffic": None, "bytes_per_step": step_bytes}}
+
+    res = {"model": "AF3-7B shape (Qwen2.5-7B backbone, 8 streams, V=%d), random bf16 weights" % len(vocab),
+           "batch": B, "prompt_tokens": T, "decode_steps": n_steps, "prefill_s": t_prefill,
+           "prefill_audio_s_per_s": B * 30.0 / t_prefill}
+    res.update(leg("bf16", dt, 2))
+    # W8A16 decode (BASELINE config 5): e4m3 copies of the streamed weights, same cache, same loop
+    model.enable_fp8_decode(True)
+    hyp, _, cache = model._greedy_device_loop(hyp[:, -1:, :], cache, "text", warm, poll=10 ** 9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hyp, _, cache = model._greedy_device_loop(hyp[:, -1:, :], cache, "text", n_steps, poll=10 ** 9)
+    torch.cuda.synchronize()
+    res["fp8_weights"] = leg("e4m3 + per-row f32 scale (W8A16), bf16 activations / KV", time.perf_counter() - t0, 1)
     del model
-    return {"model": "AF3-7B shape (Qwen2.5-7B backbone, 8 streams, V=%d), random bf16 weights" % len(vocab),
-            "batch": B, "prompt_tokens": T, "decode_steps": n_steps, "tokens_per_s": B * n_steps / dt,
-            "ms_per_step": dt / n_steps * 1e3, "prefill_s": t_prefill,
-            "prefill_audio_s_per_s": B * 30.0 / t_prefill,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                         "traffic": None, "bytes_per_step": step_bytes}}
+    return res
 
 
 def main():

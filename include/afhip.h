@@ -82,6 +82,10 @@ typedef struct {
     const void* a_norm_w; /* != NULL: A' = RMSNorm(A) with this gain [K] (modeling_qwen2.py:238-252) */
     float a_norm_eps;
     int a_swiglu;         /* != 0: A is the 32-row interleaved gate/up buffer [M, 2K], A' = silu(gate)*up */
+    /* afhip_gemm_skinny only: W is OCP e4m3 bytes [N, ldw] with one f32 scale per output row (W8A16 decode, dtype BF16,
+     * M <= 32, K % 128 == 0): C = A' . (w_scale[n] * Wq[n,:])^T.  ACT_SWIGLU is accepted here as the epilogue of a
+     * 32-row interleaved gate/up weight (N >= 8192), for both weight formats. */
+    const float* w_scale; /* != NULL selects the fp8-weight kernel */
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
@@ -194,6 +198,13 @@ typedef struct {
     const void* stream_emb;                     /* [n_stream, hidden] */
     const float* rope_cos; const float* rope_sin; /* [max_pos, hd/2] f32 (modeling_qwen2.py:91-103) */
     int rope_max_pos;
+    /* optional W8A16 copies of the weights the decode step streams (NULL = off): OCP e4m3 bytes in the same row order
+     * as the bf16 tensors + one f32 scale per output row; used when rows <= 32 and dtype is BF16 */
+    const void* const* qkv_w8; const float* const* qkv_s;
+    const void* const* o_w8; const float* const* o_s;
+    const void* const* gu_w8; const float* const* gu_s;
+    const void* const* down_w8; const float* const* down_s;
+    const void* lm_head8; const float* lm_head_s;
 } afhip_llm_weights;
 
 typedef struct {

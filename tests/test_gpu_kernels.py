@@ -396,3 +396,46 @@ def test_gemm_skinny_rmsnorm_load_swiglu_epilogue(dt, M):
     h = gf * (xf * torch.rsqrt(var + 1e-6))
     ref = F.silu(h @ gate.float().T) * (h @ up.float().T)
     _check(out, ref, *_tol(dt, (5e-5, 5e-5), (4e-2, 3e-2)), f"skinny rmsnorm+swiglu M={M}")
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(1, 768, 768, "plain"), (8, 1024, 3584, "rms"), (16, 9000, 768, "plain"), (32, 8192, 1024, "swiglu")])
+def test_gemm_skinny_fp8_weights(M, N, K, mode):
+    """W8A16 decode GEMM: e4m3 weights + per-row f32 scale against the dequantised weights in f32 (the quantisation itself
+    is the caller's; the kernel must reproduce  A' . (s_n * q[n,:])^T  to bf16 rounding)."""
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    from audio_intelligence_amd.lm.parallel import ParallelLLM
+    lib = L.lib()
+    dt = torch.bfloat16
+    xd, xf = _q(_rand(M, K, seed=91) * 2.0, dt)
+    w = _rand(N, K, seed=92, scale=0.05)
+    if mode == "swiglu":
+        I = N // 2
+        g_, u_ = w[:I], w[I:]
+        w = torch.stack([g_.reshape(I // 32, 32, K), u_.reshape(I // 32, 32, K)], dim=1).reshape(N, K)
+    q8, sc = ParallelLLM._quantize_rows_e4m3(w.to(_dev()))
+    wdq = q8.view(torch.float8_e4m3fn).float().cpu() * sc.cpu()[:, None]
+    assert float((wdq - w).abs().max()) <= 0.07 * float(w.abs().max())          # e4m3: 3 mantissa bits
+    gd, gf = _q(1 + 0.1 * _rand(K, seed=93), dt)
+    bd, bf = _q(_rand(N, seed=94, scale=0.1), dt)
+    n_out = N // 2 if mode == "swiglu" else N
+    out = torch.empty(M, n_out, dtype=dt, device=_dev())
+    g = L.GemmArgs()
+    g.A, g.W, g.C, g.w_scale = xd.data_ptr(), q8.data_ptr(), out.data_ptr(), sc.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, N, K, K, K, n_out
+    g.dtype = L.dtype_code(dt)
+    h = xf
+    if mode in ("rms", "swiglu"):
+        g.a_norm_w, g.a_norm_eps = gd.data_ptr(), 1e-6
+        h = (gf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)))
+    if mode == "swiglu":
+        g.act = L.ACT_SWIGLU
+        I = N // 2
+        wg = wdq.reshape(I // 32, 2, 32, K)[:, 0].reshape(I, K)
+        wu = wdq.reshape(I // 32, 2, 32, K)[:, 1].reshape(I, K)
+        ref = F.silu(h @ wg.T) * (h @ wu.T)
+    else:
+        g.bias = bd.data_ptr()
+        ref = h @ wdq.T + bf
+    L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+    _check(out, ref, 4e-2, 3e-2, f"skinny fp8 {mode} {M}x{N}x{K}")

@@ -175,3 +175,29 @@ def test_bf16_pipeline_tracks_fp32_tokens():
         total += len(ref)
         assert n >= 2, f"clip {i}: bf16 ids diverge from fp32 at step {n}"
     print(f"bf16 greedy prefix match: {match}/{total} tokens")
+
+
+def test_fp8_decode_weights_track_bf16():
+    """W8A16 decode (config 5): no bit-exact contract; the fp8-weight decode must stay close to the bf16 one -- the first
+    greedy tokens (large top-2 gaps) agree and the decode-step logits correlate > 0.99."""
+    _need_gpu()
+    model, pre = H.build_tiny_ualm(torch.bfloat16, DEV)
+    kw = _to_dev(_sample(1000, pre), torch.bfloat16)
+    kw.pop("loss_masks")
+    ref = model.inference_segment(CFG, cache=None, enforce_modality="text", **kw)[0][0][0][:, 0].cpu().tolist()
+    ids = torch.cat([kw["seqs"], model.assistant_token], dim=1)
+    emb = model._embed(ids, kw)
+    _, c0 = model._step(input_embeds=emb)
+    tok = model.text_token.clone()
+    lg_bf16, _ = model._step(input_ids=tok, past_key_values=c0)
+    model.enable_fp8_decode(True)
+    got = model.inference_segment(CFG, cache=None, enforce_modality="text", **kw)[0][0][0][:, 0].cpu().tolist()
+    _, c1 = model._step(input_embeds=emb)
+    lg_fp8, _ = model._step(input_ids=tok, past_key_values=c1)
+    a, b = lg_bf16[0, 0, 0].float().cpu(), lg_fp8[0, 0, 0].float().cpu()
+    corr = float(torch.corrcoef(torch.stack([a, b]))[0, 1])
+    n = 0
+    while n < min(len(got), len(ref)) and got[n] == ref[n]:
+        n += 1
+    print(f"fp8 decode: logits corr {corr:.4f}, greedy prefix match {n}/{len(ref)}")
+    assert corr > 0.99 and n >= 1
