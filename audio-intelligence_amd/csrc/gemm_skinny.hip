@@ -73,12 +73,15 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16] row sums of squares (A_RMSNORM)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int n_base = blockIdx.x * (NT * 16);
+    // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
+    // (j = b >> 1, t = b & 1) of the 32-row interleaved gate/up weight: 16-row granularity keeps the per-CU byte share even
+    const bool pair = (NT == 2) && p.swiglu_out;
+    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * 16);
 
     const char* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n_base + t * 16 + c16;
+        int n = n_base + (pair ? t * 32 : t * 16) + c16;
         n = n < p.N ? n : p.N - 1;
         wrow[t] = p.W + (long long)n * p.ldw * SZ;
     }
@@ -193,22 +196,23 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     }
     __syncthreads();
     // C/D map of the 16x16 MFMA: col (n) = lane & 15, row (m) = 4 * (lane >> 4) + reg
-    if constexpr (NT == 4) {
+    if constexpr (NT == 4 || NT == 2) {
         if (p.swiglu_out) {
-            // tiles 0,1 = 32 gate rows, tiles 2,3 = the matching 32 up rows; C is [M, N/2]
-            for (int o = tid; o < 2 * MT * 256; o += 512) {
+            // first NT/2 tiles = gate rows, last NT/2 tiles = the matching up rows (32 further in W); C is [M, N/2]
+            constexpr int NG = NT / 2;
+            for (int o = tid; o < NG * MT * 256; o += 512) {
                 const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
-                const int mt = tile % MT, nt = tile / MT;        // nt in {0,1}
+                const int mt = tile % MT, nt = tile / MT;        // gate tile
                 float g = 0.f, u = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
                     g += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
-                    u += red[((((w * NT + nt + 2) * MT + mt) * 64 + ln) << 2) + reg];
+                    u += red[((((w * NT + nt + NG) * MT + mt) * 64 + ln) << 2) + reg];
                 }
                 const int mrow = 4 * (ln >> 4) + reg;
                 const int m = mt * 16 + mrow;
-                const int n = n_base + nt * 16 + (ln & 15);       // gate row index inside W
-                if (n < p.N && m < p.M) {
+                const int ng = n_base + (pair ? 0 : nt * 16) + (ln & 15);       // gate row index inside W
+                if (ng + 32 < p.N + 1 && m < p.M) {
                     if constexpr (AMODE == A_RMSNORM) {
                         float sq = 0.f;
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
                         const float r = rsqrtf(sq / (float)p.K + p.norm_eps);
                         g *= r; u *= r;
                     }
-                    const int col = (n_base >> 1) + nt * 16 + (ln & 15);
+                    const int col = ((ng >> 6) << 5) + (ng & 31);
                     reinterpret_cast<T*>(p.C)[(long long)m * p.ldc + col] = from_f32<T>(silu(g) * u);
                 }
             }
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
 
 template <typename T, int NT, int MT>
 void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
-    const dim3 grid(cdiv(p.N, NT * 16)), block(512);
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(512);
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
     switch (amode) {
         case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM>), grid, block, lds, s, p); break;
@@ -304,9 +308,13 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     if (sw_out) AFHIP_CHECK(wide && a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm_skinny: SWIGLU epilogue needs N >= 8192, N %% 64 == 0, M <= 32, no bias/residual");
     p.swiglu_out = sw_out ? 1 : 0;
     if (a->dtype == AFHIP_BF16) {
-        if (wide) launch_mt<bf16, 4>(p, mt, amode, s); else launch_mt<bf16, 1>(p, mt, amode, s);
+        if (sw_out) launch_mt<bf16, 2>(p, mt, amode, s);
+        else if (wide) launch_mt<bf16, 4>(p, mt, amode, s);
+        else launch_mt<bf16, 1>(p, mt, amode, s);
     } else {
-        if (wide) launch_mt<float, 4>(p, mt, amode, s); else launch_mt<float, 1>(p, mt, amode, s);
+        if (sw_out) launch_mt<float, 2>(p, mt, amode, s);
+        else if (wide) launch_mt<float, 4>(p, mt, amode, s);
+        else launch_mt<float, 1>(p, mt, amode, s);
     }
     AFHIP_LAUNCH_CHECK();
     return 0;

@@ -50,12 +50,15 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int n_base = blockIdx.x * (NT * 16);
+    // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
+    // (j = b >> 1, t = b & 1) of the 32-row interleaved gate/up weight: 16-row granularity keeps the per-CU byte share even
+    const bool pair = (NT == 2) && p.swiglu_out;
+    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * 16);
 
     const char* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n_base + t * 16 + c16;
+        int n = n_base + (pair ? t * 32 : t * 16) + c16;
         n = n < p.N ? n : p.N - 1;
         wrow[t] = p.W + (long long)n * p.ldw;
     }
@@ -169,24 +172,25 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
             return 1.0f;
         }
     };
-    if constexpr (NT == 4) {
+    if constexpr (NT == 4 || NT == 2) {
         if (p.swiglu_out) {
-            for (int o = tid; o < 2 * MT * 256; o += 512) {
+            constexpr int NG = NT / 2;
+            for (int o = tid; o < NG * MT * 256; o += 512) {
                 const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
                 const int mt = tile % MT, nt = tile / MT;
                 float g = 0.f, u = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
                     g += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
-                    u += red[((((w * NT + nt + 2) * MT + mt) * 64 + ln) << 2) + reg];
+                    u += red[((((w * NT + nt + NG) * MT + mt) * 64 + ln) << 2) + reg];
                 }
                 const int mrow = 4 * (ln >> 4) + reg, m = mt * 16 + mrow;
-                const int n = n_base + nt * 16 + (ln & 15);
-                if (n + 32 < p.N + 1 && m < p.M) {
+                const int ng = n_base + (pair ? 0 : nt * 16) + (ln & 15);
+                if (ng + 32 < p.N + 1 && m < p.M) {
                     const float r = row_scale(mt, mrow);
-                    g *= r * p.wscale[n];
-                    u *= r * p.wscale[n + 32];
-                    reinterpret_cast<bf16*>(p.C)[(long long)m * p.ldc + (n_base >> 1) + nt * 16 + (ln & 15)] = (bf16)(silu(g) * u);
+                    g *= r * p.wscale[ng];
+                    u *= r * p.wscale[ng + 32];
+                    reinterpret_cast<bf16*>(p.C)[(long long)m * p.ldc + ((ng >> 6) << 5) + (ng & 31)] = (bf16)(silu(g) * u);
                 }
             }
             return;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
 
 template <int NT, int MT>
 void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
-    const dim3 grid(cdiv(p.N, NT * 16)), block(512);
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(512);
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
     if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_RMSNORM>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_PLAIN>), grid, block, lds, s, p);
@@ -248,7 +252,9 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     p.swiglu_out = sw_out ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int amode = a->a_norm_w ? A_RMSNORM : A_PLAIN;
-    if (wide) launch_mt8<4>(p, mt, amode, s); else launch_mt8<1>(p, mt, amode, s);
+    if (sw_out) launch_mt8<2>(p, mt, amode, s);
+    else if (wide) launch_mt8<4>(p, mt, amode, s);
+    else launch_mt8<1>(p, mt, amode, s);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }
