@@ -584,6 +584,10 @@ static bool use_mfma16() {
     return v == 1;
 }
 
+// persistent ping-pong kernel for the large bf16 shapes (gemm_pp.hip)
+bool gemm_pp_eligible(const afhip_gemm_args* a);
+int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s);
+
 extern "C" int afhip_prof_enable(int max_launches) {
     AFHIP_CHECK(max_launches > 0, "afhip_prof_enable: bad capacity");
     if (g_prof.cap < max_launches) {
@@ -689,7 +693,10 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     const int slot = g_prof.n;
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
-    if (big) {
+    if (gemm_pp_eligible(a)) {
+        const int rc = gemm_pp_launch(a, p.group_m, s);
+        if (rc != 0) return rc;
+    } else if (big) {
         const bool conv = a->conv_C > 0;
         const bool mf16 = a->dtype == AFHIP_BF16 && p.vec == 1 && a->act != AFHIP_ACT_SWIGLU && !a->out_f32 && use_mfma16();
         if (a->dtype == AFHIP_BF16) {

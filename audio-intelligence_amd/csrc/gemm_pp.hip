@@ -1,0 +1,381 @@
+// Persistent "ping-pong" bf16 GEMM for gfx950: C[M,N] = epilogue(A[M,K] . W[N,K]^T), the throughput path of the
+// encoder / prefill projections (afhip_gemm dispatches here when the shape qualifies, see gemm_pp_eligible).
+//
+// One 512-thread workgroup per CU walks a list of 256 x 256 output tiles.  Its 8 waves form two groups of four
+// (group = wave >> 2; waves w and w + 4 share a SIMD).  A K tile (64 deep) is processed in four PHASES, one 64 x 32
+// quadrant of the wave's 128 x 64 output per phase (16 x v_mfma_f32_16x16x32_bf16).  A phase is
+//     [LOAD section: ds_read fragments, issue one half-tile of LDS-DMA, counted vmcnt]  s_barrier
+//     [MFMA section: 16 MFMAs]                                                           s_barrier
+// and group 1 runs one barrier behind group 0, so on every SIMD one wave's MFMA section overlaps its partner's LOAD
+// section: the matrix pipe sees back-to-back MFMAs while LDS reads / DMA issue happen in the other wave.
+//
+// Operand staging: each K tile is four 16-KiB half-tiles (A0, A1, B0, B1: 128 rows x 128 B), two stages = 128 KiB of
+// LDS, filled by buffer_load_dwordx4 ... lds (no VGPR staging).  The DMA stream runs ~2 K tiles ahead of the MFMAs and
+// NEVER drains inside the loop: at most 4 half-tiles (8 DMA instructions per wave) stay in flight across barriers
+// (s_waitcnt vmcnt(8)).  The stream is continuous across output tiles, so the next tile's first K tiles land while
+// the current tile's epilogue runs, and the epilogue's global stores drain under the next tile's MFMAs.
+//
+// Schedule for K tile g in stage S = g & 1 (the quadrant order keeps B0 in registers from phase 0 to phase 3):
+//   phase 0: read A0(g), B0(g)   issue B1(g+1) -> stage S^1   wait vmcnt(8) [retires B1(g)]     MFMA (A0, B0)
+//   phase 1: read B1(g)          issue A1(g+1) -> stage S^1   wait vmcnt(8) [retires A1(g)]     MFMA (A0, B1)
+//   phase 2: read A1(g)          issue A0(g+2) -> stage S                                      MFMA (A1, B1)
+//   phase 3:                     issue B0(g+2) -> stage S     wait vmcnt(8) [A0, B0 of g+1]     MFMA (A1, B0)
+// RAW: a buffer is read one phase (>= one barrier of every wave) after the wait that retires its DMA.
+// WAR: a buffer is re-filled >= 2 phases after the phase that last read it (the staggered group's reads of phase p
+//      are retired by its lgkmcnt(0) before the barrier that opens phase p + 2's LOAD sections).
+//
+// Row maps.  A half h holds, for reading group r, tile rows r*128 + h*64 + (0..63); W half h holds, for column-wave
+// wn, the 32 output columns wn*64 + h*32 + (0..31), permuted (LDS row j*16 + 4q + k  <->  column q*8 + j*4 + k) so
+// that the 8 accumulator values a lane owns for one output row are 8 CONSECUTIVE columns: the epilogue stores (and
+// the residual loads) are 16 B per lane straight from registers, 64 contiguous bytes per row per instruction.
+// LDS image: 128-B rows, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7) (conflict-free ds_read_b128); the DMA
+// writes linearly, so the swizzle is applied to its per-lane SOURCE chunk.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
+constexpr int PP_HALF = 16384;           // 128 rows x 128 B
+constexpr int PP_STAGE = 4 * PP_HALF;    // A0 A1 B0 B1
+constexpr int PP_OFF_A0 = 0, PP_OFF_A1 = PP_HALF, PP_OFF_B0 = 2 * PP_HALF, PP_OFF_B1 = 3 * PP_HALF;
+constexpr int PP_LDS = 2 * PP_STAGE;     // 128 KiB
+
+struct PPArgs {
+    const char* A;
+    const char* W;
+    const bf16* bias;
+    const bf16* res;
+    bf16* C;
+    int M, N, K;
+    unsigned lda2, ldw2;      // row pitches in BYTES
+    long long ldc, ldres;     // elements
+    int act;
+    int tiles_m, tiles_n, group_m;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ int pp_xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = id & 7, s = id >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + s;
+}
+
+// DMA cursor: which (output tile, K tile) the stream is at.  All members are wave-uniform (SGPRs).
+struct PPCur {
+    const char* abase;   // A + m0 * lda2
+    const char* wbase;   // W + n0 * ldw2
+    unsigned anrec;      // valid bytes from abase (rows >= M read as out-of-range)
+    unsigned wnrec;
+    int koff;            // kt * 128 bytes
+    int it;              // index into this workgroup's tile list
+};
+
+__device__ __forceinline__ void pp_tile_coords(const PPArgs& p, int v, int& m0, int& n0) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = pp_xcd_remap(v, nwg);
+    const int width = p.group_m * p.tiles_n;
+    const int grp = wg / width, first_m = grp * p.group_m;
+    const int gsize = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
+    const int tm = first_m + (wg % width) % gsize, tn = (wg % width) / gsize;
+    m0 = tm * PP_BM;
+    n0 = tn * PP_BN;
+}
+
+__device__ __forceinline__ void pp_cur_set_tile(const PPArgs& p, PPCur& c, int it) {
+    int m0, n0;
+    pp_tile_coords(p, (int)blockIdx.x + it * (int)gridDim.x, m0, n0);
+    c.it = it;
+    c.koff = 0;
+    c.abase = p.A + (long long)m0 * p.lda2;
+    c.wbase = p.W + (long long)n0 * p.ldw2;
+    const int rows = (p.M - m0) < PP_BM ? (p.M - m0) : PP_BM;
+    c.anrec = (unsigned)(rows - 1) * p.lda2 + (unsigned)p.K * 2u;
+    c.wnrec = (unsigned)(PP_BN - 1) * p.ldw2 + (unsigned)p.K * 2u;
+}
+
+// next K tile of the stream; past the end of the tile list the cursor stays on the last K tile (the DMAs issued from
+// it land in buffers nobody reads again and only keep the vmcnt bookkeeping uniform)
+__device__ __forceinline__ void pp_cur_advance(const PPArgs& p, PPCur& c, int n_my) {
+    const int kend = p.K * 2 - 128;
+    if (c.koff < kend) {
+        c.koff += 128;
+    } else if (c.it + 1 < n_my) {
+        pp_cur_set_tile(p, c, c.it + 1);
+    }
+}
+
+__device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int soff, int voff0, int voff1, char* lds_dst) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, voff0, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds_dst + 8192), 16, voff1, soff, 0, 0);
+}
+
+#define PP_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define PP_BARRIER()                              \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int n_my = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nk2 = p.K / (2 * PP_BK);
+
+    // ---- DMA lane constants: instruction u of this wave fills LDS rows (u*8 + wave)*8 + lrow of a half-tile ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int src_chunk = lslot ^ (((wave & 1) << 2) + (lrow >> 1));
+    int voffA[2][2], voffB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m_local = u * 128 + h * 64 + wave * 8 + lrow;
+            voffA[h][u] = m_local * (int)p.lda2 + src_chunk * 16;
+            const int rho = (u * 8 + wave) * 8 + lrow;
+            const int pos = rho & 15;
+            const int n_local = (rho >> 5) * 64 + h * 32 + (pos >> 2) * 8 + ((rho >> 4) & 1) * 4 + (pos & 3);
+            voffB[h][u] = n_local * (int)p.ldw2 + src_chunk * 16;
+        }
+    char* const dma_dst = smem + wave * 1024;     // + stage + half offset
+
+    // ---- fragment read offsets (bytes inside a half-tile): row*128 + ((kk*4 + q) ^ swz(row))*16, swz = (c >> 1) & 7 ----
+    const int sw = (c16 >> 1) & 7;
+    const int aoff0 = (grp * 64 + c16) * 128 + ((q4 ^ sw) << 4);
+    const int aoff1 = (grp * 64 + c16) * 128 + (((4 + q4) ^ sw) << 4);
+    const int boff0 = (wn * 32 + c16) * 128 + ((q4 ^ sw) << 4);
+    const int boff1 = (wn * 32 + c16) * 128 + (((4 + q4) ^ sw) << 4);
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+
+    // ---- prologue: A0 B0 B1 A1 of stream tile 0 (stage 0), A0 B0 of stream tile 1 (stage 1) ----
+    PPCur c1, c2;
+    pp_cur_set_tile(p, c1, 0);
+    pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[0][0], voffA[0][1], dma_dst + PP_OFF_A0);
+    pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[0][0], voffB[0][1], dma_dst + PP_OFF_B0);
+    pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_OFF_B1);
+    pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], dma_dst + PP_OFF_A1);
+    pp_cur_advance(p, c1, n_my);                  // stream tile 1
+    pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[0][0], voffA[0][1], dma_dst + PP_STAGE + PP_OFF_A0);
+    pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[0][0], voffB[0][1], dma_dst + PP_STAGE + PP_OFF_B0);
+    c2 = c1;
+    pp_cur_advance(p, c2, n_my);                  // stream tile 2
+    PP_WAIT_VM8();                                // A0(0), B0(0) of this wave have landed
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();                   // stagger: group 1 runs one barrier behind group 0
+
+    auto mfma_quad = [&](auto ha_tag, auto hb_tag, bf16x8 (&fbx)[2][2]) {
+        constexpr int HA = decltype(ha_tag)::value, HB = decltype(hb_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto read_a = [&](const char* half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *reinterpret_cast<const bf16x8*>(half + aoff0 + i * 2048);
+            fa[i][1] = *reinterpret_cast<const bf16x8*>(half + aoff1 + i * 2048);
+        }
+    };
+    auto read_b = [&](const char* half, bf16x8 (&fbx)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fbx[j][0] = *reinterpret_cast<const bf16x8*>(half + boff0 + j * 2048);
+            fbx[j][1] = *reinterpret_cast<const bf16x8*>(half + boff1 + j * 2048);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // one K tile in stage S
+    auto ktile = [&](auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        const char* st = smem + S * PP_STAGE;
+        char* d_same = dma_dst + S * PP_STAGE;
+        char* d_other = dma_dst + (S ^ 1) * PP_STAGE;
+        // phase 0
+        read_b(st + PP_OFF_B0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(st + PP_OFF_A0);
+        pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], d_other + PP_OFF_B1);
+        PP_WAIT_VM8();
+        PP_BARRIER();
+        mfma_quad(I0{}, I0{}, fb0);
+        PP_BARRIER();
+        // phase 1
+        read_b(st + PP_OFF_B1, fb1);
+        pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1);
+        PP_WAIT_VM8();
+        PP_BARRIER();
+        mfma_quad(I0{}, I1{}, fb1);
+        PP_BARRIER();
+        // phase 2
+        read_a(st + PP_OFF_A1);
+        pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0);
+        PP_BARRIER();
+        mfma_quad(I1{}, I1{}, fb1);
+        PP_BARRIER();
+        // phase 3
+        pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0);
+        PP_WAIT_VM8();
+        PP_BARRIER();
+        mfma_quad(I1{}, I0{}, fb0);
+        PP_BARRIER();
+        c1 = c2;
+        pp_cur_advance(p, c2, n_my);
+    };
+
+    for (int it = 0; it < n_my; ++it) {
+        for (int k2 = 0; k2 < nk2; ++k2) {
+            ktile(I0{});
+            ktile(I1{});
+        }
+        // ---- epilogue straight from registers (no LDS, no barrier): lane (c, q) owns, for each of its 8 rows, the 8
+        //      consecutive columns q*8 .. q*8+7 of both 32-column halves of the wave's 64 columns ----
+        int m0, n0;
+        pp_tile_coords(p, (int)blockIdx.x + it * (int)gridDim.x, m0, n0);
+        const int ncol = n0 + wn * 64 + q4 * 8;
+        float bv[2][8];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            if constexpr (HAS_BIAS) {
+                const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(p.bias + ncol + hb * 32);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[hb][e] = (float)b8[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[hb][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                const bool ok = m < p.M;
+                bf16x8 r8[2];
+                if constexpr (HAS_RES) {
+                    if (ok) {
+                        r8[0] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol);
+                        r8[1] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol + 32);
+                    }
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
+                        if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
+                        if constexpr (HAS_RES) v += (float)r8[hb][e];
+                        o[e] = (bf16)v;
+                    }
+                    if (ok) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ncol + hb * 32) = o;
+                    acc[ha][i][hb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[ha][i][hb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+    }
+    if (grp == 0) PP_BARRIER();                   // pairs with group 1's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+bool pp_enabled() {
+    const char* e = getenv("AFHIP_GEMM_PP");   // A/B switch for benchmarking (read per call so one process can compare)
+    return !(e && e[0] == '0');
+}
+
+int pp_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int ACT, bool HB, bool HR>
+void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
+}
+
+}  // namespace
+
+// Shapes the ping-pong kernel takes: bf16 in / bf16 out, no implicit conv, no SwiGLU pairing, whole 256-column tiles,
+// an even number of 64-deep K tiles, 16-byte aligned rows everywhere, operands addressable with 32-bit byte offsets.
+bool gemm_pp_eligible(const afhip_gemm_args* a) {
+    if (!pp_enabled()) return false;
+    if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0) return false;
+    if (a->act != AFHIP_ACT_NONE && a->act != AFHIP_ACT_GELU) return false;
+    if (a->M < 1024 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
+    if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
+    if (a->bias && ((uintptr_t)a->bias % 16)) return false;
+    if (a->residual && ((a->ldres % 8) || ((uintptr_t)a->residual % 16))) return false;
+    if ((long long)a->lda * 2 * PP_BM >= (1ll << 31) || (long long)a->ldw * 2 * PP_BN >= (1ll << 31)) return false;
+    return true;
+}
+
+int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
+    PPArgs p;
+    p.A = (const char*)a->A; p.W = (const char*)a->W;
+    p.bias = (const bf16*)a->bias; p.res = (const bf16*)a->residual; p.C = (bf16*)a->C;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda2 = (unsigned)(a->lda * 2); p.ldw2 = (unsigned)(a->ldw * 2);
+    p.ldc = a->ldc; p.ldres = a->ldres;
+    p.act = a->act;
+    p.tiles_m = cdiv(a->M, PP_BM); p.tiles_n = a->N / PP_BN; p.group_m = group_m;
+    const long long nwg = (long long)p.tiles_m * p.tiles_n;
+    AFHIP_CHECK(nwg < (1ll << 30), "afhip_gemm: grid too large");
+    const int ncu = pp_num_cus();
+    const int grid = nwg < ncu ? (int)nwg : ncu;
+    const bool hb = a->bias != nullptr, hr = a->residual != nullptr;
+    if (a->act == AFHIP_ACT_GELU) {
+        if (hb && hr) pp_launch_t<AFHIP_ACT_GELU, true, true>(p, grid, s);
+        else if (hb) pp_launch_t<AFHIP_ACT_GELU, true, false>(p, grid, s);
+        else if (hr) pp_launch_t<AFHIP_ACT_GELU, false, true>(p, grid, s);
+        else pp_launch_t<AFHIP_ACT_GELU, false, false>(p, grid, s);
+    } else {
+        if (hb && hr) pp_launch_t<AFHIP_ACT_NONE, true, true>(p, grid, s);
+        else if (hb) pp_launch_t<AFHIP_ACT_NONE, true, false>(p, grid, s);
+        else if (hr) pp_launch_t<AFHIP_ACT_NONE, false, true>(p, grid, s);
+        else pp_launch_t<AFHIP_ACT_NONE, false, false>(p, grid, s);
+    }
+    return 0;
+}

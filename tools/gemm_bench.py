@@ -32,4 +32,15 @@ for name, m, n, k, act, res in shapes:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n_it
-    print(f"{name:14s} M={m:6d} N={n:5d} K={k:5d}  {ms:8.3f} ms  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+    # vendor-library ceiling on the same device and data: torch.matmul -> hipBLASLt / rocBLAS (plain GEMM, no epilogue)
+    wt = w.t()
+    for _ in range(3):
+        torch.matmul(a, wt, out=out)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n_it):
+        torch.matmul(a, wt, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_lib = e0.elapsed_time(e1) / n_it
+    print(f"{name:14s} M={m:6d} N={n:5d} K={k:5d}  {ms:8.3f} ms  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s   | hipBLASLt plain {ms_lib:8.3f} ms {2.0*m*n*k/ms_lib/1e9:8.1f} TFLOP/s", flush=True)
