@@ -277,19 +277,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 for (int e = 0; e < 8; ++e) bv[hb][e] = 0.f;
             }
         }
+        // residual: all 16 loads of the lane are issued before the first use (one exposed latency per tile instead of
+        // eight); rows past M are clamped for the load and masked at the store
+        bf16x8 r8[2][4][2];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                    m = m < p.M ? m : p.M - 1;
+                    r8[ha][i][0] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol);
+                    r8[ha][i][1] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol + 32);
+                }
+        }
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
                 const bool ok = m < p.M;
-                bf16x8 r8[2];
-                if constexpr (HAS_RES) {
-                    if (ok) {
-                        r8[0] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol);
-                        r8[1] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol + 32);
-                    }
-                }
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     bf16x8 o;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     for (int e = 0; e < 8; ++e) {
                         float v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
                         if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
-                        if constexpr (HAS_RES) v += (float)r8[hb][e];
+                        if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
                         o[e] = (bf16)v;
                     }
                     if (ok) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ncol + hb * 32) = o;
