@@ -693,7 +693,8 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     const int slot = g_prof.n;
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
-    if (gemm_pp_eligible(a)) {
+    const bool use_pp = gemm_pp_eligible(a);
+    if (use_pp) {
         const int rc = gemm_pp_launch(a, p.group_m, s);
         if (rc != 0) return rc;
     } else if (big) {
@@ -718,7 +719,7 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     if (rec) {
         (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
         g_prof.flops[slot] = 2.0 * (double)a->M * (double)a->N * (double)a->K;
-        g_prof.dtype[slot] = a->dtype;
+        g_prof.dtype[slot] = a->dtype | (use_pp ? AFHIP_PROF_PINGPONG : 0);
         g_prof.n = slot + 1;
     }
     AFHIP_LAUNCH_CHECK();

@@ -91,7 +91,10 @@ int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
 /* Measurement hook for bench.py's roofline leg: while enabled, every afhip_gemm launch is bracketed by HIP events on
  * its own stream; collect() waits for them and returns the launch count, summed milliseconds and summed
- * algorithmic FLOPs (2*M*N*K) of the launches of `dtype`, then disables recording. Not for production paths. */
+ * algorithmic FLOPs (2*M*N*K) of the launches of `dtype`, then disables recording. Not for production paths.
+ * Launches served by the persistent ping-pong kernel (gemm_pp.hip) are recorded as `dtype | AFHIP_PROF_PINGPONG`, so the
+ * roofline leg can quote that kernel alone (its rocprofv3 rows) and the remaining launches separately. */
+#define AFHIP_PROF_PINGPONG 0x100
 int afhip_prof_enable(int max_launches);
 int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops);
 
