@@ -16,6 +16,7 @@
 #include "common.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +40,9 @@ struct Tables {
     static constexpr size_t COFF = BAND + 2 * NMEL;                   // [NMEL] int32 offset of the mel's weights in CW
     static constexpr size_t CW = COFF + NMEL;                         // [CWMAX] non-zero weights, mel-major
     static constexpr size_t CWMAX = 512;
-    static constexpr size_t TOTAL = CW + CWMAX;
+    static constexpr size_t TW200 = CW + CWMAX;                       // [200][2] e^{-2 pi i j / 200} (FFT path)
+    static constexpr size_t WINF = TW200 + 400;                       // [400] periodic Hann window (FFT path)
+    static constexpr size_t TOTAL = WINF + 400;
 };
 
 __device__ __forceinline__ int float_order_key(float f) {
@@ -47,6 +50,41 @@ __device__ __forceinline__ int float_order_key(float f) {
     return i >= 0 ? i : i ^ 0x7fffffff;
 }
 __device__ __forceinline__ float float_from_key(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+
+// Banded mel + log10 tail shared by both pass-1 forms: thread (m = tid & 127, half = tid >> 7) keeps its mel's <= KCMAX
+// band weights in registers and walks every second frame of the tile; the KCMAX power reads of a frame are independent
+// (fixed trip count, masked), so their LDS latency overlaps -- the data-dependent `for k < count` loop this replaces
+// serialised one LDS round trip per band element.  Returns the running max of the values it wrote.
+constexpr int KCMAX = 12;
+template <int NFR, int PITCH>
+__device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
+                                          float* __restrict__ scratch, int b, int t0, int tid) {
+    const int m = tid & 127;
+    const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
+    float wk[KCMAX];
+#pragma unroll
+    for (int k = 0; k < KCMAX; ++k) wk[k] = k < kc ? cw[wo + k] : 0.f;
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int f = tid >> 7; f < NFR; f += 2) {
+        const int t = t0 + f;
+        if (t >= NFRAMES) break;
+        float pv[KCMAX];
+#pragma unroll
+        for (int k = 0; k < KCMAX; ++k) {
+            const int kk = k < kc ? k0 + k : k0;          // stay inside this frame's row
+            pv[k] = pw[f * PITCH + kk];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCMAX; ++k) acc = fmaf(wk[k], pv[k], acc);   // same left-to-right order as the reference's band sum
+        const float v = log10f(fmaxf(acc, 1e-10f));
+        scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
+        mx = fmaxf(mx, v);
+    }
+    return mx;
+}
 
 __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wav, int n_samples, long long wav_stride,
                                                     const float* __restrict__ tab, float* __restrict__ scratch,
@@ -197,20 +235,216 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
     __syncthreads();
 
     // ---- banded mel + log10 (weights and band table in LDS: no dependent global loads); scratch is [B][3000][128] f32 ----
-    float mx = -INFINITY;
-    {
-        const int m = tid & 127;
-        const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
-        for (int f = tid >> 7; f < FT; f += 2) {
-            const int t = t0 + f;
-            if (t >= NFRAMES) break;
-            float acc = 0.f;
-            for (int k = 0; k < kc; ++k) acc += cw[wo + k] * pw[f * PROW + k0 + k];
-            const float v = log10f(fmaxf(acc, 1e-10f));
-            scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
-            mx = fmaxf(mx, v);
+    float mx = mel_tail<FT, PROW>(pw, cw, cband, scratch, b, t0, tid);
+    mx = wave_max(mx);
+    if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Pass 1, FFT form (default): the 400-point real DFT of a frame costs ~12 kFLOP as a mixed-radix FFT against 160 kFLOP
+// for the folded DFT products above, which moves the kernel from the f32-MFMA roof towards the HBM roof.
+//   * one workgroup = 32 frames of one clip; a frame is owned by 8 adjacent lanes;
+//   * the windowed frame is packed as 200 complex points z[n] = x[2n] + i x[2n+1]; lane t takes the decimated
+//     sequence z[8m + t], m = 0..24, and runs a 25-point DFT entirely in registers (5 x 5 Cooley-Tukey, radix-5
+//     butterflies), multiplies by the twiddle e^{-2 pi i t q / 200}, and the 8 lanes finish with a radix-2
+//     decimation-in-frequency DFT-8 ACROSS lanes (three lane^4 / lane^2 / lane^1 exchanges); lane t then holds
+//     Z[q + 25 bitrev3(t)], q = 0..24;
+//   * the real-input spectrum is unpacked from Z[k] and conj Z[200-k] (lane ^ 7, register 25 - q), power -> LDS,
+//     then the same banded mel / log10 / running-max tail as the DFT form.
+constexpr int FFT_FT = 32;                 // frames per workgroup
+constexpr int FFT_PITCH = 176;             // LDS floats per hop row: 176 f mod 64 = 0, 48, 32, 16 -> the 4 frames of a 32-lane group hit disjoint banks
+constexpr int FFT_ROWS = FFT_FT + 2;       // hops touched: 31 + ceil(400 / 160)
+constexpr int FFT_PROW = 203;              // LDS pitch of the power tile
+constexpr int FFT_MAIN = (FFT_ROWS * FFT_PITCH > FFT_FT * FFT_PROW) ? FFT_ROWS * FFT_PITCH : FFT_FT * FFT_PROW;
+
+constexpr float W25R[17] = {1.000000000e+00f, 9.685831611e-01f, 8.763066800e-01f, 7.289686274e-01f, 5.358267950e-01f, 3.090169944e-01f, 6.279051953e-02f, -1.873813146e-01f, -4.257792916e-01f, -6.374239897e-01f, -8.090169944e-01f, -9.297764859e-01f, -9.921147013e-01f, -9.921147013e-01f, -9.297764859e-01f, -8.090169944e-01f, -6.374239897e-01f};
+constexpr float W25I[17] = {-0.000000000e+00f, -2.486898872e-01f, -4.817536741e-01f, -6.845471059e-01f, -8.443279255e-01f, -9.510565163e-01f, -9.980267284e-01f, -9.822872507e-01f, -9.048270525e-01f, -7.705132428e-01f, -5.877852523e-01f, -3.681245527e-01f, -1.253332336e-01f, 1.253332336e-01f, 3.681245527e-01f, 5.877852523e-01f, 7.705132428e-01f};
+constexpr float W400R[25] = {1.000000000e+00f, 9.998766325e-01f, 9.995065604e-01f, 9.988898750e-01f, 9.980267284e-01f, 9.969173337e-01f, 9.955619646e-01f, 9.939609555e-01f, 9.921147013e-01f, 9.900236577e-01f, 9.876883406e-01f, 9.851093262e-01f, 9.822872507e-01f, 9.792228106e-01f, 9.759167619e-01f, 9.723699204e-01f, 9.685831611e-01f, 9.645574185e-01f, 9.602936857e-01f, 9.557930148e-01f, 9.510565163e-01f, 9.460853588e-01f, 9.408807690e-01f, 9.354440308e-01f, 9.297764859e-01f};
+constexpr float W400I[25] = {-0.000000000e+00f, -1.570731731e-02f, -3.141075908e-02f, -4.710645071e-02f, -6.279051953e-02f, -7.845909573e-02f, -9.410831332e-02f, -1.097343111e-01f, -1.253332336e-01f, -1.409012319e-01f, -1.564344650e-01f, -1.719291003e-01f, -1.873813146e-01f, -2.027872954e-01f, -2.181432414e-01f, -2.334453639e-01f, -2.486898872e-01f, -2.638730500e-01f, -2.789911060e-01f, -2.940403252e-01f, -3.090169944e-01f, -3.239174182e-01f, -3.387379202e-01f, -3.534748438e-01f, -3.681245527e-01f};
+__device__ const float W16R[8] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 0.f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f};
+__device__ const float W16I[8] = {0.f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f};
+
+// lane exchanges inside an 8-lane group as DPP moves (VALU, no LDS round trip): lane ^ 1, ^ 2 (quad_perm), ^ 4 (row_shl:4 on
+// lanes 0-3 / 8-11 + row_shr:4 on lanes 4-7 / 12-15 of each 16-lane row), ^ 7 (row_half_mirror)
+__device__ __forceinline__ float lane_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float lane_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float lane_xor4(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    int a = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);
+    a = __builtin_amdgcn_update_dpp(a, x, 0x114, 0xF, 0xA, false);
+    return __builtin_bit_cast(float, a);
+}
+__device__ __forceinline__ float lane_xor7(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
+
+// forward 5-point DFT in place: y_k = sum_n x_n e^{-2 pi i n k / 5}
+__device__ __forceinline__ void dft5(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3,
+                                     float& r4, float& i4) {
+    constexpr float C1 = 3.090169944e-01f, C2 = -8.090169944e-01f, S1 = 9.510565163e-01f, S2 = 5.877852523e-01f;
+    const float t1r = r1 + r4, t1i = i1 + i4, t2r = r2 + r3, t2i = i2 + i3;
+    const float t3r = r1 - r4, t3i = i1 - i4, t4r = r2 - r3, t4i = i2 - i3;
+    const float a1r = r0 + C1 * t1r + C2 * t2r, a1i = i0 + C1 * t1i + C2 * t2i;
+    const float a2r = r0 + C2 * t1r + C1 * t2r, a2i = i0 + C2 * t1i + C1 * t2i;
+    const float b1r = S1 * t3r + S2 * t4r, b1i = S1 * t3i + S2 * t4i;
+    const float b2r = S2 * t3r - S1 * t4r, b2i = S2 * t3i - S1 * t4i;
+    r0 = r0 + t1r + t2r; i0 = i0 + t1i + t2i;
+    r1 = a1r + b1i; i1 = a1i - b1r;      // a1 - i b1
+    r4 = a1r - b1i; i4 = a1i + b1r;      // a1 + i b1
+    r2 = a2r + b2i; i2 = a2i - b2r;
+    r3 = a2r - b2i; i3 = a2i + b2r;
+}
+
+__global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
+                                                        const float* __restrict__ tab, float* __restrict__ scratch,
+                                                        int* __restrict__ clipmax, unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#define LM_STAMP(k) do { if (dbg && blockIdx.x == 40 && blockIdx.y == 0 && threadIdx.x == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    LM_STAMP(0);
+    float* xs = reinterpret_cast<float*>(smem_raw);          // [FFT_ROWS][FFT_PITCH] samples, later [FFT_FT][FFT_PROW] power
+    float* tw = xs + FFT_MAIN;                               // [200][2] e^{-2 pi i j / 200}
+    float* wn = tw + 400;                                    // [400] window
+    float* cw = wn + 400;                                    // [CWMAX] compact mel weights
+    int* cband = reinterpret_cast<int*>(cw + Tables::CWMAX); // [NMEL][3] first bin, count, offset
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FFT_FT;
+    const float* w = wav + (long long)b * wav_stride;
+
+    for (int i = tid; i < 400; i += 256) { tw[i] = tab[Tables::TW200 + i]; wn[i] = tab[Tables::WINF + i]; }
+    for (int i = tid; i < (int)Tables::CWMAX; i += 256) cw[i] = tab[Tables::CW + i];
+    for (int i = tid; i < NMEL; i += 256) {
+        const int* band_g = reinterpret_cast<const int*>(tab + Tables::BAND);
+        cband[3 * i] = band_g[2 * i];
+        cband[3 * i + 1] = band_g[2 * i + 1];
+        cband[3 * i + 2] = reinterpret_cast<const int*>(tab + Tables::COFF)[i];
+    }
+    // ---- stage samples (same conventions as the DFT form): padded index p = t0*160 + s, original i = p - 200 ----
+    constexpr int NSTAGE = (FFT_FT - 1) * HOP + NFFT;       // 5360 samples = 1340 float4
+    constexpr int NV4 = NSTAGE / 4, V4_PER_THREAD = (NV4 + 255) / 256;
+    const int ibase = t0 * HOP - NFFT / 2;
+    const bool interior = ibase >= 0 && ibase + NSTAGE <= n_samples && (n_samples <= NSAMP) && ((wav_stride & 3) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
+    f32x4 sv[V4_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < V4_PER_THREAD; ++u) {
+        const int v = tid + 256 * u;
+        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (v < NV4) {
+            if (interior) {
+                sv[u] = *reinterpret_cast<const f32x4*>(w + ibase + 4 * v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int i = ibase + 4 * v + e;
+                    if (i < 0) i = -i;
+                    if (i >= NSAMP) i = 2 * (NSAMP - 1) - i;
+                    if (i >= 0 && i < n_samples) sv[u][e] = w[i];
+                }
+            }
         }
     }
+#pragma unroll
+    for (int u = 0; u < V4_PER_THREAD; ++u) {
+        const int v = tid + 256 * u;
+        if (v < NV4) {
+            const int sidx = 4 * v;                          // 160 % 4 == 0: the 4 samples share a hop row
+            *reinterpret_cast<f32x4*>(xs + (sidx / HOP) * FFT_PITCH + (sidx % HOP)) = sv[u];
+        }
+    }
+    __syncthreads();
+
+    LM_STAMP(1);
+    // ---- per-lane constants ----
+    const int f = tid >> 3, t = tid & 7;
+    const int k1 = ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1);            // bitrev3(t): this lane ends with Z[q + 25 k1]
+    const float s4 = (t & 4) ? -1.f : 1.f, s2 = (t & 2) ? -1.f : 1.f, s1 = (t & 1) ? -1.f : 1.f;
+    float wa_r = 1.f, wa_i = 0.f, wb_r = 1.f, wb_i = 0.f;                  // DIF twiddles of the lane^4 and lane^2 stages
+    if (t & 4) { wa_r = W16R[2 * (t & 3)]; wa_i = W16I[2 * (t & 3)]; }     // e^{-2 pi i (t & 3) / 8}
+    if (t & 2) { wb_r = W16R[4 * (t & 1)]; wb_i = W16I[4 * (t & 1)]; }     // e^{-2 pi i (t & 1) / 4}
+    const float lr = W16R[k1], li = W16I[k1];                               // e^{-2 pi i 25 k1 / 400}
+    const int k1p = (8 - k1) & 7;
+    const int src0 = (lane & ~7) | (((k1p & 1) << 2) | (k1p & 2) | ((k1p >> 2) & 1));   // lane holding Z[200 - 25 k1]
+
+    // ---- load + window: z[m] = (x[16m + 2t], x[16m + 2t + 1]) . w ----
+    float zr[25], zi[25];
+#pragma unroll
+    for (int m = 0; m < 25; ++m) {
+        const f32x2 xv = *reinterpret_cast<const f32x2*>(xs + (f + m / 10) * FFT_PITCH + 16 * (m % 10) + 2 * t);
+        const f32x2 wv = *reinterpret_cast<const f32x2*>(wn + 16 * m + 2 * t);
+        zr[m] = xv[0] * wv[0];
+        zi[m] = xv[1] * wv[1];
+    }
+    LM_STAMP(2);
+    // ---- 25-point DFT in registers: m = 5 m1 + m2, output index k = ka + 5 kb ----
+#pragma unroll
+    for (int m2 = 0; m2 < 5; ++m2)
+        dft5(zr[m2], zi[m2], zr[5 + m2], zi[5 + m2], zr[10 + m2], zi[10 + m2], zr[15 + m2], zi[15 + m2], zr[20 + m2], zi[20 + m2]);
+    // now zr[5 ka + m2] = A[ka][m2]; twiddle by W25^{m2 ka}
+#pragma unroll
+    for (int ka = 1; ka < 5; ++ka)
+#pragma unroll
+        for (int m2 = 1; m2 < 5; ++m2) {
+            const float wr = W25R[m2 * ka], wi = W25I[m2 * ka];
+            const float ar = zr[5 * ka + m2], ai = zi[5 * ka + m2];
+            zr[5 * ka + m2] = ar * wr - ai * wi;
+            zi[5 * ka + m2] = ar * wi + ai * wr;
+        }
+#pragma unroll
+    for (int ka = 0; ka < 5; ++ka)
+        dft5(zr[5 * ka], zi[5 * ka], zr[5 * ka + 1], zi[5 * ka + 1], zr[5 * ka + 2], zi[5 * ka + 2], zr[5 * ka + 3], zi[5 * ka + 3],
+             zr[5 * ka + 4], zi[5 * ka + 4]);
+    // zr[5 ka + kb] = Y[ka + 5 kb]; gather into natural order yq[q], q = ka + 5 kb, with the inter-stage twiddle e^{-2 pi i t q / 200}
+    float yr[25], yi[25];
+#pragma unroll
+    for (int ka = 0; ka < 5; ++ka)
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            const int q = ka + 5 * kb;
+            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw + 2 * (t * q));
+            const float ar = zr[5 * ka + kb], ai = zi[5 * ka + kb];
+            yr[q] = ar * tv[0] - ai * tv[1];
+            yi[q] = ar * tv[1] + ai * tv[0];
+        }
+    LM_STAMP(3);
+    // ---- DFT-8 across the 8 lanes of the frame (decimation in frequency) ----
+#pragma unroll
+    for (int q = 0; q < 25; ++q) {
+        float orr = lane_xor4(yr[q]), oii = lane_xor4(yi[q]);
+        float ur = orr + s4 * yr[q], ui = oii + s4 * yi[q];
+        yr[q] = ur * wa_r - ui * wa_i; yi[q] = ur * wa_i + ui * wa_r;
+        orr = lane_xor2(yr[q]); oii = lane_xor2(yi[q]);
+        ur = orr + s2 * yr[q]; ui = oii + s2 * yi[q];
+        yr[q] = ur * wb_r - ui * wb_i; yi[q] = ur * wb_i + ui * wb_r;
+        orr = lane_xor1(yr[q]); oii = lane_xor1(yi[q]);
+        yr[q] = orr + s1 * yr[q]; yi[q] = oii + s1 * yi[q];
+    }
+    LM_STAMP(4);
+    __syncthreads();   // every lane of the workgroup is done with the samples: LDS becomes the power tile
+    LM_STAMP(5);
+
+    // ---- unpack the real-input spectrum: X[k] = E + W400^k O, E = (Z[k] + conj Z[200-k]) / 2, O = -i (Z[k] - conj Z[200-k]) / 2 ----
+    float* pw = xs + f * FFT_PROW;
+    {
+        const float pr0 = __shfl(yr[0], src0, 64), pi0 = __shfl(yi[0], src0, 64);
+#pragma unroll
+        for (int q = 0; q < 25; ++q) {
+            float pr, pi;
+            if (q == 0) { pr = pr0; pi = pi0; }
+            else { pr = lane_xor7(yr[25 - q]); pi = lane_xor7(yi[25 - q]); }
+            const float er = 0.5f * (yr[q] + pr), ei = 0.5f * (yi[q] - pi);
+            const float o_r = 0.5f * (yi[q] + pi), o_i = -0.5f * (yr[q] - pr);
+            const float wr = W400R[q] * lr - W400I[q] * li, wi = W400R[q] * li + W400I[q] * lr;
+            const float xr = er + wr * o_r - wi * o_i, xi = ei + wr * o_i + wi * o_r;
+            pw[q + 25 * k1] = xr * xr + xi * xi;
+        }
+        if (t == 0) { const float x200 = yr[0] - yi[0]; pw[200] = x200 * x200; }
+    }
+    __syncthreads();
+
+    // ---- banded mel + log10; scratch is [B][3000][128] f32 ----
+    LM_STAMP(6);
+    float mx = mel_tail<FFT_FT, FFT_PROW>(xs, cw, cband, scratch, b, t0, tid);
+    LM_STAMP(7);
     mx = wave_max(mx);
     if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
 }
@@ -266,6 +500,11 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
             if (n < 200) t[Tables::SIN + (size_t)k * KPAD + i] = (float)(-sin(two_pi * (double)kn / NFFT));
         }
     for (int i = 0; i < 200; ++i) t[Tables::WIN + i] = (float)(0.5 - 0.5 * cos(two_pi * (double)(i + 1) / NFFT));
+    for (int j = 0; j < 200; ++j) {
+        t[Tables::TW200 + 2 * j] = (float)cos(two_pi * (double)j / 200.0);
+        t[Tables::TW200 + 2 * j + 1] = (float)(-sin(two_pi * (double)j / 200.0));
+    }
+    for (int n = 0; n < NFFT; ++n) t[Tables::WINF + n] = (float)(0.5 - 0.5 * cos(two_pi * (double)n / NFFT));
     memcpy(t + Tables::FILT, filters_host, sizeof(float) * NBIN * NMEL);
     int* band = reinterpret_cast<int*>(t + Tables::BAND);
     for (int m = 0; m < NMEL; ++m) {
@@ -274,6 +513,7 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
             if (filters_host[k * NMEL + m] != 0.f) { if (lo < 0) lo = k; hi = k; }
         band[2 * m] = lo < 0 ? 0 : lo;
         band[2 * m + 1] = lo < 0 ? 0 : hi - lo + 1;
+        AFHIP_CHECK(band[2 * m + 1] <= KCMAX, "afhip_log_mel_tables_host: mel %d spans %d bins (> %d)", m, band[2 * m + 1], KCMAX);
     }
     int* coff = reinterpret_cast<int*>(t + Tables::COFF);
     int off = 0;
@@ -305,9 +545,19 @@ extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_str
     int* clipmax = reinterpret_cast<int*>(workspace);
     float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * sizeof(int) + 255) / 256 * 256);
     hipLaunchKernelGGL(logmel_init_max, dim3(cdiv(B, 256)), dim3(256), 0, s, clipmax, B);
-    const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL);
-    hipLaunchKernelGGL(logmel_pass1, dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
-                       tables, scratch, clipmax);
+    static int use_dft = -1;
+    if (use_dft < 0) { const char* e = getenv("AFHIP_LOGMEL_DFT"); use_dft = (e && e[0] == '1') ? 1 : 0; }   // A/B switch: the folded-DFT MFMA form
+    if (use_dft) {
+        const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL);
+        hipLaunchKernelGGL(logmel_pass1, dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+                           tables, scratch, clipmax);
+    } else {
+        const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL);
+        const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
+        unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
+        hipLaunchKernelGGL(logmel_pass1_fft, dim3(cdiv(NFRAMES, FFT_FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+                           tables, scratch, clipmax, dbg);
+    }
     const dim3 g2(cdiv(NFRAMES, 32), B);
     if (out_dtype == AFHIP_F32) {
         if (layout == 0) hipLaunchKernelGGL((logmel_pass2<float, 0>), g2, dim3(256), 0, s, scratch, clipmax, (float*)mel_out);

@@ -9,3 +9,12 @@ wav = torch.randn(B, 480000, device="cuda") * 0.1
 for _ in range(5):
     fe.extract_device(wav, layout="btc", dtype=torch.bfloat16)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ws = None
+e0.record()
+for _ in range(20):
+    fe.extract_device(wav, layout="btc", dtype=torch.bfloat16)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"log-mel B={B}: {ms*1e3:.1f} us  {B*3456000/ms/1e6:.1f} GB/s algorithmic  ({B*30/ms*1e3:.0f} audio-s/s)")
