@@ -89,6 +89,7 @@ SIGNATURES = {
     "afhip_avgpool_ln": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "afhip_rmsnorm": (_I, [_P, _P, _P, _I, _I, _F, _I, _P]),
     "afhip_embed_sum": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "afhip_gather_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "afhip_rope_kv": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "afhip_transpose_cast": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "afhip_attention": (_I, [C.POINTER(AttnArgs), _P]),

@@ -232,6 +232,37 @@ extern "C" int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, in
     return 0;
 }
 
+
+// Row gather of the AF3 / Qwen2-Audio placeholder merge (modeling_whisper.py:1056-1104): out row r is text row plan[r]
+// (plan >= 0), audio row -(plan[r] + 2) (plan <= -2) or zeros (plan == -1, padding).  One wave per row, 16 B per lane.
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ text, const char* __restrict__ audio,
+                                                          const int32_t* __restrict__ plan, char* __restrict__ out,
+                                                          int n_rows, int row_bytes) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int pl = plan[row];
+    const char* src = pl >= 0 ? text + (long long)pl * row_bytes : (pl <= -2 ? audio + (long long)(-(pl + 2)) * row_bytes : nullptr);
+    char* dst = out + (long long)row * row_bytes;
+    for (int off = lane * 16; off < row_bytes; off += 64 * 16) {
+        const u32x4 v = src ? ld16(src + off) : u32x4{0u, 0u, 0u, 0u};
+        st16(dst + off, v);
+    }
+}
+}  // namespace
+
+extern "C" int afhip_gather_rows(const void* text_rows, const void* audio_rows, const int32_t* plan, void* out, int n_rows,
+                                 int n_text_rows, int n_audio_rows, int row_bytes, void* stream) {
+    AFHIP_CHECK(plan && out && n_rows > 0, "afhip_gather_rows: bad args n_rows=%d", n_rows);
+    AFHIP_CHECK(row_bytes > 0 && row_bytes % 16 == 0, "afhip_gather_rows: row_bytes=%d must be a positive multiple of 16", row_bytes);
+    AFHIP_CHECK((n_text_rows == 0 || text_rows) && (n_audio_rows == 0 || audio_rows), "afhip_gather_rows: null source with rows to read");
+    AFHIP_CHECK(((uintptr_t)out % 16) == 0 && ((uintptr_t)text_rows % 16) == 0 && ((uintptr_t)audio_rows % 16) == 0, "afhip_gather_rows: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, (const char*)text_rows,
+                       (const char*)audio_rows, plan, (char*)out, n_rows, row_bytes);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int afhip_embed_sum(const int64_t* ids, const void* table, void* out, int n_tok, int S, int H, int vocab, int dtype, void* stream) {
     AFHIP_CHECK(dtype == AFHIP_F32 || dtype == AFHIP_BF16, "afhip_embed_sum: bad dtype %d", dtype);
     AFHIP_CHECK(ids && table && out && n_tok > 0 && S > 0 && H > 0 && H % 8 == 0 && vocab > 0, "afhip_embed_sum: bad args n_tok=%d S=%d H=%d vocab=%d", n_tok, S, H, vocab);

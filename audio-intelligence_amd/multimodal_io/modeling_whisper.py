@@ -257,3 +257,97 @@ class AFWhisperEncoder(nn.Module):
         if return_dict is False:
             return (out,)
         return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)
+
+
+class Qwen2AudioMultiModalProjector(nn.Module):
+    """Drop-in for modeling_whisper.py:768-775: `linear` (d_model -> hidden_size, bias) over the encoder output, as one
+    afhip_gemm with the bias in its epilogue.  Accepts either the reference's nested config (audio_config.d_model /
+    text_config.hidden_size) or two integers."""
+
+    def __init__(self, config=None, d_model: Optional[int] = None, hidden_size: Optional[int] = None):
+        super().__init__()
+        if config is not None:
+            d_model, hidden_size = config.audio_config.d_model, config.text_config.hidden_size
+        self.linear = _Linear(d_model, hidden_size, bias=True)
+
+    def forward(self, audio_features: torch.Tensor) -> torch.Tensor:
+        x = audio_features.contiguous()
+        y = ops.gemm(x.reshape(-1, x.shape[-1]), self.linear.weight, bias=self.linear.bias)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+
+def merge_input_ids_with_audio_features(audio_features, num_audio_tokens, inputs_embeds, input_ids, attention_mask, labels=None, *,
+                                        audio_token_index: int, pad_token_id: int = -1, ignore_index: int = -100,
+                                        padding_side: str = "left"):
+    """Drop-in for Qwen2AudioForConditionalGeneration._merge_input_ids_with_audio_features (modeling_whisper.py:913-1108):
+    every <|AUDIO|> placeholder of `input_ids` widens to the `num_audio_tokens` rows of its audio, text embeddings keep
+    their order, the batch is re-padded on the side the attention mask shows (or `padding_side` when it cannot tell).
+
+    Returns the reference's 5-tuple (final_embedding [B, L', H], final_attention_mask, final_labels | None, position_ids,
+    final_input_ids) on the device of `inputs_embeds`.  The int64 index plan (cumsum of token widths, :1021-1096) is a
+    few hundred integers and is built on the host; the embedding rows move through ONE HIP row gather
+    (afhip_gather_rows) instead of three index_put passes over a zero-filled tensor.  Raises the reference's ValueErrors
+    (:1017-1019 both mask edges zero, :1098-1102 audio rows != placeholder slots)."""
+    import numpy as np
+    dev = inputs_embeds.device
+    if dev.type != "cuda":
+        raise L.AfhipError("merge_input_ids_with_audio_features runs on the GPU only (no CPU fallback)")
+    n_audio, max_tok, H = audio_features.shape
+    B, Lseq = input_ids.shape
+    ids = input_ids.detach().cpu().numpy().astype(np.int64)
+    am = attention_mask.detach().cpu().numpy().astype(np.int64)
+    nat = num_audio_tokens.detach().cpu().numpy().astype(np.int64)
+    lp, rp = bool((am[:, 0] == 0).any()), bool((am[:, -1] == 0).any())
+    left_padding = True
+    if B > 1:
+        if lp and not rp:
+            left_padding = True
+        elif not lp and rp:
+            left_padding = False
+        elif not lp and not rp:
+            left_padding = padding_side == "left"
+        else:
+            raise ValueError(f"both side of attention_mask has zero, invalid. {attention_mask}")
+    special = ids == audio_token_index
+    if int(special.sum()) != nat.shape[0]:
+        raise ValueError(f"The input provided to the model are wrong. The number of audio tokens is {special.sum(-1)} while"
+                         f" the number of audio given to the model is {n_audio}. This prevents correct indexing and breaks batch generation.")
+    width = np.ones_like(ids)
+    width[special] = nat                       # row-major order of appearance == stacking order of the audios
+    new_pos = np.cumsum(width, -1) - 1
+    M = int(width.sum(-1).max())
+    if left_padding:
+        new_pos = new_pos + (M - 1 - new_pos[:, -1])[:, None]
+    tb, ts = np.nonzero((~special) & (am == 1))
+    td = new_pos[tb, ts]
+    plan = np.full((B, M), -1, np.int64)       # -1 = zero row
+    audio_slot = np.ones((B, M), bool)
+    audio_slot[tb, td] = False
+    valid = width.sum(-1) - (am == 0).sum(-1)
+    seq = np.arange(M)[None, :]
+    audio_slot &= ((M - seq) <= valid[:, None]) if left_padding else (seq < valid[:, None])
+    if int(audio_slot.sum()) != int(nat.sum()):
+        raise ValueError(f"The input provided to the model are wrong. The number of audio tokens is {special.sum(-1)} while"
+                         f" the number of audio given to the model is {n_audio}. This prevents correct indexing and breaks batch generation.")
+    keep = np.arange(max_tok)[None, :] < nat[:, None]
+    audio_rows = np.flatnonzero(keep.reshape(-1))                    # row index into audio_features.view(-1, H), stacking order
+    plan[tb, td] = tb * Lseq + ts                                     # row index into inputs_embeds.view(-1, H)
+    plan.reshape(-1)[np.flatnonzero(audio_slot.reshape(-1))] = -(audio_rows + 2)
+    fmask = np.zeros((B, M), np.int64)
+    fmask[tb, td] = am[tb, ts]
+    fmask |= audio_slot
+    fids = np.full((B, M), pad_token_id, np.int64)
+    fids[tb, td] = ids[tb, ts]
+    pos = np.cumsum(fmask, -1) - 1
+    pos[fmask == 0] = 1
+    final_labels = None
+    if labels is not None:
+        lab = labels.detach().cpu().numpy().astype(np.int64)
+        fl = np.full((B, M), ignore_index, np.int64)
+        fl[tb, td] = lab[tb, ts]
+        final_labels = torch.from_numpy(fl).to(dev)
+    feats = audio_features.to(device=dev, dtype=inputs_embeds.dtype).contiguous()
+    plan_d = torch.from_numpy(plan.reshape(-1).astype(np.int32)).to(dev)
+    emb = ops.gather_rows(inputs_embeds.contiguous().view(-1, H), feats.view(-1, H), plan_d, B * M).view(B, M, H)
+    return (emb, torch.from_numpy(fmask).to(device=dev, dtype=attention_mask.dtype), final_labels,
+            torch.from_numpy(pos).to(dev), torch.from_numpy(fids).to(device=dev, dtype=input_ids.dtype))

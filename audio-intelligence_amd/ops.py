@@ -94,6 +94,19 @@ def embed_sum(ids: torch.Tensor, table: torch.Tensor):
     return out.view(*ids.shape[:-1], table.shape[1])
 
 
+def gather_rows(text_rows: torch.Tensor, audio_rows: torch.Tensor, plan: torch.Tensor, n_rows: int):
+    """out[r] = text_rows[plan[r]] (plan >= 0) | audio_rows[-(plan[r] + 2)] (plan <= -2) | 0 (plan == -1); rows are [*, H]."""
+    lib = L.lib()
+    _chk(text_rows, "gather_rows.text_rows")
+    assert text_rows.is_contiguous() and audio_rows.is_contiguous() and plan.dtype == torch.int32 and plan.is_contiguous()
+    assert text_rows.dtype == audio_rows.dtype and text_rows.shape[-1] == audio_rows.shape[-1]
+    H = text_rows.shape[-1]
+    out = torch.empty((n_rows, H), dtype=text_rows.dtype, device=text_rows.device)
+    L.check(lib.afhip_gather_rows(L.ptr(text_rows), L.ptr(audio_rows), L.ptr(plan), L.ptr(out), n_rows, text_rows.numel() // H,
+                                  audio_rows.numel() // H, H * text_rows.element_size(), L.stream_ptr()))
+    return out
+
+
 def transpose_cast(x: torch.Tensor, out_dtype=None):
     """[B,R,C] -> [B,C,R] (+ dtype change)."""
     lib = L.lib()

@@ -115,6 +115,13 @@ int afhip_gemm_skinny(const afhip_gemm_args* args, void* stream);
 int afhip_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, int dtype, void* stream);
 int afhip_avgpool_ln(const void* x, const void* w, const void* b, void* y, int B, int Tout, int D, float eps, int dtype, void* stream);
 int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float eps, int dtype, void* stream);
+/* Row gather of the AF3 / Qwen2-Audio placeholder merge: replaces the three index_put / masked assignments of
+ * Qwen2AudioForConditionalGeneration._merge_input_ids_with_audio_features (modeling_whisper.py:1056-1104).
+ * plan [n_rows] int32 (device): >= 0 text row index into text_rows [n_text_rows, row_bytes]; <= -2 audio row -(v + 2) of
+ * audio_rows [n_audio_rows, row_bytes]; -1 zero row (padding).  The host builds the plan (int64 index math of :1021-1096)
+ * and range-checks it; n_text_rows / n_audio_rows are carried for the null-pointer checks only. */
+int afhip_gather_rows(const void* text_rows, const void* audio_rows, const int32_t* plan, void* out, int n_rows,
+                      int n_text_rows, int n_audio_rows, int row_bytes, void* stream);
 int afhip_embed_sum(const int64_t* ids, const void* table, void* out, int n_tok, int S, int H, int vocab, int dtype, void* stream);
 int afhip_rope_kv(void* qkv, int ld_qkv, const float* cos_table, const float* sin_table, int pos0,
                   void* k_cache, void* v_cache, int B, int T, int n_q, int n_kv, int hd, int cache_cap,

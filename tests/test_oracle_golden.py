@@ -2,7 +2,10 @@
 
 CPU-only (`-m "not gpu"`).  Tolerances: the oracle is fp32 PyTorch-CPU like the reference, so
 activations agree to a few ulp-scale 1e-5; ids / lengths / index tables are exact."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 import oracle
@@ -151,3 +154,43 @@ def test_full_shape_encoder():
     mel = torch.from_numpy(H.mel_of(2000, 480000))[None]
     out = oracle.afwhisper.encoder_forward(mel, sd, cfg)
     np.testing.assert_allclose(_rows(out[0].numpy()), arr["enc_full_s30_final"], atol=2e-4, rtol=0)
+
+
+# ---- AF3 / Qwen2-Audio placeholder merge (modeling_whisper.py:913-1108) ----
+def _merge_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_merge.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    for n in names:
+        ins = {k.split("/")[2]: z[k] for k in z.files if k.startswith(n + "/in/")}
+        outs = {k.split("/")[2]: z[k] for k in z.files if k.startswith(n + "/out/")}
+        yield n, ins, outs, str(z[n + "/padding_side"])
+
+
+def test_merge_oracle_matches_reference_golden():
+    from oracle import merge as om
+    n_cases = 0
+    for name, ins, outs, side in _merge_cases():
+        emb, mask, lab, pos, ids = om.merge_input_ids_with_audio_features(
+            ins["audio_features"], ins["num_audio_tokens"], ins["inputs_embeds"], ins["input_ids"], ins["attention_mask"],
+            ins.get("labels"), audio_token_index=99, pad_token_id=-1, ignore_index=-100, padding_side=side)
+        assert np.array_equal(emb, outs["final_embedding"]), name          # pure copies: bit-exact
+        assert np.array_equal(mask, outs["final_attention_mask"]), name
+        assert np.array_equal(pos, outs["position_ids"]), name
+        assert np.array_equal(ids, outs["final_input_ids"]), name
+        if "final_labels" in outs:
+            assert np.array_equal(lab, outs["final_labels"]), name
+        else:
+            assert lab is None
+        n_cases += 1
+    assert n_cases == 8
+
+
+def test_merge_oracle_rejects_what_the_reference_rejects():
+    from oracle import merge as om
+    ids = np.array([[1, 99, 2], [3, 4, 5]])
+    feats = np.zeros((1, 4, 2), np.float32)
+    emb = np.zeros((2, 3, 2), np.float32)
+    with pytest.raises(ValueError):      # zeros on both edges of the mask (modeling_whisper.py:1017-1019)
+        om.merge_plan([4], ids, np.array([[0, 1, 1], [1, 1, 0]]), 99)
+    with pytest.raises(ValueError):      # audio rows offered != placeholder slots (modeling_whisper.py:1098-1102)
+        om.merge_input_ids_with_audio_features(np.zeros((2, 4, 2), np.float32), [4, 2], emb, ids, np.ones((2, 3), np.int64), None, 99)
