@@ -265,6 +265,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         int m0, n0;
         pp_tile_coords(p, (int)blockIdx.x + it * (int)gridDim.x, m0, n0);
         const int ncol = n0 + wn * 64 + q4 * 8;
+        if constexpr (ACT == AFHIP_ACT_SWIGLU) {
+            // gate / up rows are interleaved in 32-row blocks (ParallelLLM.pack): this wave's first 32 columns are the gate,
+            // its second 32 the up projection of the same 32 outputs; C is [M, N/2]
+            const int ocol = ((n0 + wn * 64) >> 1) + q4 * 8;
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)(silu(acc[ha][i][0][e >> 2][e & 3]) * acc[ha][i][1][e >> 2][e & 3]);
+                    if (m < p.M) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ocol) = o;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        acc[ha][i][hb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[ha][i][hb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            continue;
+        }
         float bv[2][8];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -345,13 +366,13 @@ void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
 
 }  // namespace
 
-// Shapes the ping-pong kernel takes: bf16 in / bf16 out, no implicit conv, no SwiGLU pairing, whole 256-column tiles,
+// Shapes the ping-pong kernel takes: bf16 in / bf16 out, no implicit conv, whole 256-column tiles,
 // an even number of 64-deep K tiles, 16-byte aligned rows everywhere, operands addressable with 32-bit byte offsets.
 bool gemm_pp_eligible(const afhip_gemm_args* a) {
     if (!pp_enabled()) return false;
     if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0) return false;
-    if (a->act != AFHIP_ACT_NONE && a->act != AFHIP_ACT_GELU) return false;
-    if (a->M < 1024 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
+    if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
+    if (a->M < 512 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
     if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
     if (a->bias && ((uintptr_t)a->bias % 16)) return false;
     if (a->residual && ((a->ldres % 8) || ((uintptr_t)a->residual % 16))) return false;
@@ -373,7 +394,9 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     const int ncu = pp_num_cus();
     const int grid = nwg < ncu ? (int)nwg : ncu;
     const bool hb = a->bias != nullptr, hr = a->residual != nullptr;
-    if (a->act == AFHIP_ACT_GELU) {
+    if (a->act == AFHIP_ACT_SWIGLU) {
+        pp_launch_t<AFHIP_ACT_SWIGLU, false, false>(p, grid, s);
+    } else if (a->act == AFHIP_ACT_GELU) {
         if (hb && hr) pp_launch_t<AFHIP_ACT_GELU, true, true>(p, grid, s);
         else if (hb) pp_launch_t<AFHIP_ACT_GELU, true, false>(p, grid, s);
         else if (hr) pp_launch_t<AFHIP_ACT_GELU, false, true>(p, grid, s);

@@ -41,6 +41,22 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
 MEL_BYTES_PER_CLIP = 480000 * 4 + 128 * 3000 * 4      # read wav + write f32 mel
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+    (profiles/r01_hbm_traffic_pmc.json, unit and gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  PMC passes
+    serialise every dispatch, so they are collected offline and only READ here; None when the file is absent."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")) as f:
+            k = json.load(f)["kernels_r01_e"]
+        pp = [v for name, v in k.items() if name.startswith("gemm_pp_kernel")]
+        n = sum(v["launches_sampled"] for v in pp)
+        gemm = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in pp) / n     # launch-weighted mean over qkv / out / fc1 / fc2
+        mel = k["logmel_pass1_fft"]["hbm_bytes_per_launch"] + k["logmel_pass2"]["hbm_bytes_per_launch"]
+        return gemm, mel
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None, None
+
+
 def enc_flops_per_clip(c):
     d, f, Lr, T = c["d_model"], c["encoder_ffn_dim"], c["encoder_layers"], c["max_source_positions"]
     stem = 2 * 3000 * d * 3 * c["num_mel_bins"] + 2 * T * d * 3 * d
@@ -274,6 +290,7 @@ def main():
     if rank == 0:
         audio_s = world * args.steps * B * 30.0
         gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        gemm_traffic, mel_traffic = pmc_traffic()
         mel_gbs = MEL_BYTES_PER_CLIP * B / (mel_ms * 1e-3) / 1e9
         res = {
             "metric": "audio-seconds encoded/sec (log-mel + AF-Whisper encoder)", "value": audio_s / elapsed, "unit": "audio-s/s",
@@ -285,14 +302,15 @@ def main():
                        "encoder_tflop_per_clip": enc_flops_per_clip(ENC_CFG) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (persistent ping-pong bf16 GEMM: the qkv / out / fc1 / fc2 projections, 128 launches per forward)",
                          "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches": n_l.value, "avg_launch_ms": ms.value / max(1, n_l.value),
+                         "traffic": gemm_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic_pmc.json; algorithmic A+W+C+residual bytes: 0.25-0.63 GB)",
+                         "launches": n_l.value, "avg_launch_ms": ms.value / max(1, n_l.value),
                          "avg_launch_gflop": fl.value / max(1, n_l.value) / 1e9, "gemm_share_of_step": ms.value / (elapsed * 1e3) if world == 1 else None,
                          "other_gemm": {"kernel": "gemm256_kernel (implicit-conv stem)", "launches": n_o.value,
                                         "avg_launch_ms": ms_o.value / max(1, n_o.value),
                                         "tflops": fl_o.value / (ms_o.value * 1e-3) / 1e12 if ms_o.value > 0 else 0.0}},
             "stages": {"mel_ms": mel_ms, "mel_audio_s_per_s": B * 30.0 / (mel_ms * 1e-3),
                        "mel_roofline": {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": mel_gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_clip": MEL_BYTES_PER_CLIP},
+                                        "frac": mel_gbs / PEAK_HBM_GBS, "traffic": mel_traffic, "bytes_per_clip": MEL_BYTES_PER_CLIP},
                        "encoder_ms": enc_ms, "encoder_audio_s_per_s": B * 30.0 / (enc_ms * 1e-3),
                        "encoder_tflops": enc_flops_per_clip(ENC_CFG) * B / (enc_ms * 1e-3) / 1e12},
         }

@@ -439,3 +439,78 @@ def test_gemm_skinny_fp8_weights(M, N, K, mode):
         ref = h @ wdq.T + bf
     L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
     _check(out, ref, 4e-2, 3e-2, f"skinny fp8 {mode} {M}x{N}x{K}")
+
+
+def test_gemm_pingpong_persistent_path():
+    """gemm_pp.hip (bf16, N % 256 == 0, K % 128 == 0, M >= 1024): every epilogue variant, an M edge tile, more tiles than CUs
+    (several tiles per persistent workgroup, DMA stream crossing tile boundaries), the minimum K, and agreement with the
+    256x256 one-barrier kernel it replaces (AFHIP_GEMM_PP=0)."""
+    import os
+    from audio_intelligence_amd import ops, _lib as L
+    dt = torch.bfloat16
+    tol = (2e-2, 2e-2)
+    cases = [(1024, 256, 128), (1500, 512, 1280), (20000, 1280, 256), (3000, 3840, 1280), (2049, 256, 5120)]
+    for ci, (M, N, K) in enumerate(cases):
+        ad, af = _q(_rand(M, K, seed=60 + ci), dt)
+        wd, wf = _q(_rand(N, K, seed=70 + ci, scale=0.03), dt)
+        bd, bf = _q(_rand(N, seed=80 + ci, scale=0.1), dt)
+        rd, rf = _q(_rand(M, N, seed=90 + ci), dt)
+        base = af @ wf.T
+        for act in (L.ACT_NONE, L.ACT_GELU):
+            for hb in (False, True):
+                for hr in (False, True):
+                    ref = base + (bf if hb else 0.0)
+                    if act == L.ACT_GELU:
+                        ref = F.gelu(ref)
+                    if hr:
+                        ref = ref + rf
+                    c = ops.gemm(ad, wd, bias=bd if hb else None, act=act, residual=rd if hr else None)
+                    _check(c, ref, *tol, f"pp gemm {M}x{N}x{K} act={act} bias={hb} res={hr}")
+        os.environ["AFHIP_GEMM_PP"] = "0"
+        try:
+            c_old = ops.gemm(ad, wd, bias=bd, act=L.ACT_GELU, residual=rd)
+        finally:
+            os.environ.pop("AFHIP_GEMM_PP", None)
+        c_new = ops.gemm(ad, wd, bias=bd, act=L.ACT_GELU, residual=rd)
+        assert float((c_new.float() - c_old.float()).abs().max()) <= 0.07, "ping-pong vs one-barrier kernel"   # <= 1 bf16 ulp at |x| <= 8
+    # in-place residual (out-proj / fc2 of the encoder: h += x @ W^T)
+    M, N, K = 1500, 1280, 1280
+    ad, af = _q(_rand(M, K, seed=101), dt)
+    wd, wf = _q(_rand(N, K, seed=102, scale=0.03), dt)
+    hd, hf = _q(_rand(M, N, seed=103), dt)
+    ops.gemm(ad, wd, residual=hd, out=hd)
+    _check(hd, af @ wf.T + hf, *tol, "pp in-place residual")
+    # A = I against asymmetric integers: exact, catches any row / column permutation of the LDS image or the epilogue
+    eye = torch.zeros(1024, 256); eye[:256] = torch.eye(256)
+    wi = ((torch.arange(512)[:, None] * 5 + torch.arange(256)[None, :] * 3) % 61 - 30).float()
+    ed, _ = _q(eye, dt); wid, wif = _q(wi, dt)
+    c = ops.gemm(ed, wid).float().cpu()
+    assert torch.equal(c[:256], wif.T.contiguous()) and float(c[256:].abs().max()) == 0.0
+
+
+def test_attention_software_pipelined_opt_in():
+    """attention_pp.hip (AFHIP_ATTN_PP=1): encoder shape, ragged key lengths, a spike that forces the lagged-max rescale."""
+    import os
+    from audio_intelligence_amd import ops
+    os.environ["AFHIP_ATTN_PP"] = "1"
+    try:
+        for (B, T, H, lens, spike) in [(2, 1500, 4, None, False), (3, 700, 2, [700, 333, 65], False), (2, 1500, 2, [1500, 1], True)]:
+            d = H * 64
+            g = torch.Generator().manual_seed(7)
+            qkv = torch.randn(B, T, 3 * d, generator=g)
+            if spike:
+                qkv[:, T // 2, d:2 * d] *= 6.0
+            qd = qkv.to(torch.bfloat16).to(_dev())
+            qf = qd.float().cpu()
+            kl = torch.tensor(lens, dtype=torch.int32, device=_dev()) if lens else None
+            out = ops.attention_packed(qd, H, key_len=kl).float().cpu()
+            q, k, v = [x.reshape(B, T, H, 64).permute(0, 2, 1, 3) for x in qf.split(d, dim=2)]
+            s = q @ k.transpose(-1, -2) / 8.0
+            if lens:
+                mask = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
+                s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+            ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, d)
+            assert not torch.isnan(out).any()
+            assert float((out - ref).abs().max()) <= (0.06 if spike else 0.02), f"attention_pp B={B} T={T} lens={lens}"
+    finally:
+        os.environ.pop("AFHIP_ATTN_PP", None)
