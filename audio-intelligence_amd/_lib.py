@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("dtype", C.c_int), ("act", C.c_int), ("res_row_mod", C.c_int),
                 ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int),
                 ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
-                ("w_scale", C.c_void_p)]
+                ("w_scale", C.c_void_p),
+                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_bias", C.c_void_p), ("row_stats_out", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -47,7 +48,9 @@ class EncoderWeights(C.Structure):
                 ("ln1_w", c_void_pp), ("ln1_b", c_void_pp), ("qkv_w", c_void_pp), ("qkv_b", c_void_pp),
                 ("out_w", c_void_pp), ("out_b", c_void_pp), ("ln2_w", c_void_pp), ("ln2_b", c_void_pp),
                 ("fc1_w", c_void_pp), ("fc1_b", c_void_pp), ("fc2_w", c_void_pp), ("fc2_b", c_void_pp),
-                ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p)]
+                ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p),
+                ("qkv_wf", c_void_pp), ("qkv_cs", c_void_pp), ("qkv_bf", c_void_pp),
+                ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp)]
 
 
 class LlmWeights(C.Structure):
@@ -90,6 +93,8 @@ SIGNATURES = {
     "afhip_rmsnorm": (_I, [_P, _P, _P, _I, _I, _F, _I, _P]),
     "afhip_embed_sum": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "afhip_gather_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "afhip_ln_stats_finalize": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
+    "afhip_row_stats": (_I, [_P, _I, _I, C.c_float, _I, _P, _P]),
     "afhip_rope_kv": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "afhip_transpose_cast": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "afhip_attention": (_I, [C.POINTER(AttnArgs), _P]),

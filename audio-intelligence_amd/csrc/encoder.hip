@@ -4,6 +4,7 @@
 //   stem : conv1 (implicit GEMM, +bias, GELU) -> conv2 (stride 2, +bias, GELU, + position table)
 //   layer: LN -> fused QKV GEMM (k bias = 0) -> flash attention -> out-proj GEMM (+bias, +residual in place)
 //          LN -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias, +residual in place)
+//          (bf16 throughput mode: both LNs folded into the GEMMs around them, see `fold` below)
 //   tail : AvgPool1d(2,2) + LayerNorm fused
 #include "common.h"
 
@@ -15,6 +16,8 @@ struct EncWs {
     char* ln;    // [B*Tp, d]
     char* qkv;   // [B*Tp, 3d]
     char* att;   // [B*Tp, d]
+    float* part; // [d/64][B*Tp][2] row (sum, sum of squares) partials of the stored residual stream (LayerNorm-folded mode)
+    float* stats;// [B*Tp][2] row (mean, rstd)
     size_t total;
 };
 
@@ -33,13 +36,16 @@ EncWs carve(const afhip_encoder_weights* w, int B, char* base) {
     ws.ln = take(rows * d * sz);
     ws.qkv = take(rows * 3 * d * sz);
     ws.att = take(rows * d * sz);
+    ws.part = (float*)take((d / 64 + 1) * rows * 2 * sizeof(float));
+    ws.stats = (float*)take(rows * 2 * sizeof(float));
     ws.total = off;
     return ws;
 }
 
 int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-         int ldres, int dtype, int act, int row_mod, hipStream_t s, int cTin = 0, int cTout = 0, int cStride = 0, int cC = 0) {
-    afhip_gemm_args g;
+         int ldres, int dtype, int act, int row_mod, hipStream_t s, int cTin = 0, int cTout = 0, int cStride = 0, int cC = 0,
+         const float* ln_stats = nullptr, const float* ln_colsum = nullptr, const float* ln_bias = nullptr, float* row_stats_out = nullptr) {
+    afhip_gemm_args g = {};
     g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
@@ -47,6 +53,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
     g.conv_Tin = cTin; g.conv_Tout = cTout; g.conv_stride = cStride; g.conv_C = cC;
     g.out_f32 = 0;
     g.a_norm_w = nullptr; g.a_norm_eps = 0.f; g.a_swiglu = 0; g.w_scale = nullptr;
+    g.ln_stats = ln_stats; g.ln_colsum = ln_colsum; g.ln_bias = ln_bias; g.row_stats_out = row_stats_out;
     return afhip_gemm(&g, s);
 }
 
@@ -88,9 +95,13 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
     }
 
+    // LayerNorm-folded mode (bf16, ping-pong-GEMM shapes): the two LayerNorms of a layer never write a normalised copy of the
+    // stream.  out-proj / fc2 emit row (sum, sum of squares) partials of what they store, a 3-us finalize turns them into
+    // (mean, rstd), and q/k/v / fc1 run on the RAW stream with gamma folded into their weights (afhip.h).
+    const bool fold = dt == AFHIP_BF16 && w->qkv_wf && w->qkv_cs && w->qkv_bf && w->fc1_wf && w->fc1_cs && w->fc1_bf &&
+                      rows >= 512 && d % 256 == 0 && f % 256 == 0;
+    const int P = d / 64;
     for (int l = 0; l < w->n_layers; ++l) {
-        if ((rc = afhip_layernorm(ws.h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
-        if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         afhip_attn_args a;
         a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = ws.att;
         a.key_len = feat_len;
@@ -100,11 +111,29 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         a.q_head_stride = hd; a.kv_head_stride = hd;
         a.o_head_stride = 0; a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         a.causal = 0; a.q_pos0 = 0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
-        if ((rc = afhip_attention(&a, s))) return rc;
-        if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
-        if ((rc = afhip_layernorm(ws.h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
-        if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
-        if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        if (fold) {
+            if (l == 0 && (rc = afhip_row_stats(ws.h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
+            if ((rc = gemm(ws.h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+                           ws.stats, w->qkv_cs[l], w->qkv_bf[l], nullptr))) return rc;
+            if ((rc = afhip_attention(&a, s))) return rc;
+            if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+                           nullptr, nullptr, nullptr, ws.part))) return rc;
+            if ((rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats, s))) return rc;
+            if ((rc = gemm(ws.h, w->fc1_wf[l], nullptr, nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s, 0, 0, 0, 0,
+                           ws.stats, w->fc1_cs[l], w->fc1_bf[l], nullptr))) return rc;
+            const bool last = l + 1 == w->n_layers;
+            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+                           nullptr, nullptr, nullptr, last ? nullptr : ws.part))) return rc;
+            if (!last && (rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats, s))) return rc;
+        } else {
+            if ((rc = afhip_layernorm(ws.h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+            if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            if ((rc = afhip_attention(&a, s))) return rc;
+            if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            if ((rc = afhip_layernorm(ws.h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+            if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
+            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+        }
         if (hidden_out && hidden_layer == l) {
             if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
         }

@@ -694,6 +694,7 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     const int slot = g_prof.n;
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot], s);
     const bool use_pp = gemm_pp_eligible(a);
+    AFHIP_CHECK(use_pp || (!a->ln_stats && !a->row_stats_out), "afhip_gemm: the LayerNorm-folded forms need the ping-pong kernel's shape (bf16, N %% 256 == 0, K %% 128 == 0, M >= 512)");
     if (use_pp) {
         const int rc = gemm_pp_launch(a, p.group_m, s);
         if (rc != 0) return rc;

@@ -53,6 +53,10 @@ struct PPArgs {
     long long ldc, ldres;     // elements
     int act;
     int tiles_m, tiles_n, group_m;
+    const float* ln_stats;    // LNFOLD: [M][2] row mean, rstd
+    const float* ln_colsum;   // LNFOLD: [N] sum_k W'[n,k]
+    const float* ln_bias;     // LNFOLD: [N] f32 bias (b + W beta)
+    float* stats_out;         // STATS: [N/64][M][2] partial (sum, sum of squares) of the stored rows
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -121,7 +125,7 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool LNFOLD, bool STATS>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -286,16 +290,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 }
             continue;
         }
-        float bv[2][8];
+        float bv[2][8], cv[2][8];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            if constexpr (HAS_BIAS) {
+            if constexpr (LNFOLD) {
+                // LayerNorm folded into this GEMM: A is the raw residual stream, W' = W diag(gamma), and
+                //   LN(x) W^T + b = rstd[m] (x W'^T - mean[m] colsum[n]) + (b + W beta)[n]
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + hb * 32), c1 = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + hb * 32 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_bias + ncol + hb * 32), b1 = *reinterpret_cast<const f32x4*>(p.ln_bias + ncol + hb * 32 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cv[hb][e] = c0[e]; cv[hb][4 + e] = c1[e]; bv[hb][e] = b0[e]; bv[hb][4 + e] = b1[e]; }
+            } else if constexpr (HAS_BIAS) {
                 const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(p.bias + ncol + hb * 32);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bv[hb][e] = (float)b8[e];
+                for (int e = 0; e < 8; ++e) { bv[hb][e] = (float)b8[e]; cv[hb][e] = 0.f; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bv[hb][e] = 0.f;
+                for (int e = 0; e < 8; ++e) { bv[hb][e] = 0.f; cv[hb][e] = 0.f; }
             }
         }
         // residual: all 16 loads of the lane are issued before the first use (one exposed latency per tile instead of
@@ -312,27 +323,68 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     r8[ha][i][1] = *reinterpret_cast<const bf16x8*>(p.res + (long long)m * p.ldres + ncol + 32);
                 }
         }
+        // LNFOLD: the 8 (mean, rstd) pairs of the lane's rows, issued together like the residual
+        f32x2 st2[2][4];
+        if constexpr (LNFOLD) {
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                    m = m < p.M ? m : p.M - 1;
+                    st2[ha][i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)m);
+                }
+        }
+        float rs[2][4], rss[2][4];
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
                 const bool ok = m < p.M;
+                float mean = 0.f, rstd = 1.f;
+                if constexpr (LNFOLD) { mean = st2[ha][i][0]; rstd = st2[ha][i][1]; }
+                rs[ha][i] = 0.f; rss[ha][i] = 0.f;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
+                        float v;
+                        if constexpr (LNFOLD) v = fmaf(rstd, fmaf(-mean, cv[hb][e], acc[ha][i][hb][e >> 2][e & 3]), bv[hb][e]);
+                        else v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
                         if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
                         if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
                         o[e] = (bf16)v;
+                        if constexpr (STATS) { const float r = (float)o[e]; rs[ha][i] += r; rss[ha][i] = fmaf(r, r, rss[ha][i]); }
                     }
                     if (ok) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ncol + hb * 32) = o;
                     acc[ha][i][hb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
                     acc[ha][i][hb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+        if constexpr (STATS) {
+            // row statistics of what was STORED (the next LayerNorm's input), summed over this wave's 64 columns: the 4 lanes
+            // c16 + 16 q own a row.  All 32 exchanges are issued back to back; the [N/64][M] partials are merged by
+            // afhip_ln_stats_finalize
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { rs[ha][i] += __shfl_xor(rs[ha][i], 16, 64); rss[ha][i] += __shfl_xor(rss[ha][i], 16, 64); }
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { rs[ha][i] += __shfl_xor(rs[ha][i], 32, 64); rss[ha][i] += __shfl_xor(rss[ha][i], 32, 64); }
+            if (q4 == 0) {
+#pragma unroll
+                for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                        if (m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long long)((n0 >> 6) + wn) * p.M + m)) = f32x2{rs[ha][i], rss[ha][i]};
+                    }
+            }
+        }
     }
     if (grp == 0) PP_BARRIER();                   // pairs with group 1's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -354,14 +406,14 @@ int pp_num_cus() {
     return n;
 }
 
-template <int ACT, bool HB, bool HR>
+template <int ACT, bool HB, bool HR, bool LF = false, bool ST = false>
 void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
+    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
 }
 
 }  // namespace
@@ -372,6 +424,8 @@ bool gemm_pp_eligible(const afhip_gemm_args* a) {
     if (!pp_enabled()) return false;
     if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0) return false;
     if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
+    if (a->ln_stats && (a->act == AFHIP_ACT_SWIGLU || a->residual || a->row_stats_out || !a->ln_colsum || !a->ln_bias)) return false;
+    if (a->row_stats_out && (a->act != AFHIP_ACT_NONE || !a->bias || !a->residual)) return false;
     if (a->M < 512 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
     if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
     if (a->bias && ((uintptr_t)a->bias % 16)) return false;
@@ -394,7 +448,13 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     const int ncu = pp_num_cus();
     const int grid = nwg < ncu ? (int)nwg : ncu;
     const bool hb = a->bias != nullptr, hr = a->residual != nullptr;
-    if (a->act == AFHIP_ACT_SWIGLU) {
+    p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_bias = a->ln_bias; p.stats_out = a->row_stats_out;
+    if (a->ln_stats) {
+        if (a->act == AFHIP_ACT_GELU) pp_launch_t<AFHIP_ACT_GELU, false, false, true, false>(p, grid, s);
+        else pp_launch_t<AFHIP_ACT_NONE, false, false, true, false>(p, grid, s);
+    } else if (a->row_stats_out) {
+        pp_launch_t<AFHIP_ACT_NONE, true, true, false, true>(p, grid, s);
+    } else if (a->act == AFHIP_ACT_SWIGLU) {
         pp_launch_t<AFHIP_ACT_SWIGLU, false, false>(p, grid, s);
     } else if (a->act == AFHIP_ACT_GELU) {
         if (hb && hr) pp_launch_t<AFHIP_ACT_GELU, true, true>(p, grid, s);

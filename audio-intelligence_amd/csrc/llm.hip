@@ -42,7 +42,7 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
 int gemm_any(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
              int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s, const void* norm_w = nullptr,
              float norm_eps = 0.f, int a_swiglu = 0, const float* w_scale = nullptr) {
-    afhip_gemm_args g;
+    afhip_gemm_args g = {};
     g.A = A; g.W = W; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldres = ldres;

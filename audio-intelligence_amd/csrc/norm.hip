@@ -233,6 +233,74 @@ extern "C" int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, in
 }
 
 
+// ---- LayerNorm statistics for the GEMM-folded form (afhip.h: afhip_gemm_args.ln_stats) ----
+namespace {
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int rows, float inv_d, float eps,
+                                                                float* __restrict__ stats) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f, ss = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(part + 2 * ((long long)p * rows + r));
+        s += v[0]; ss += v[1];
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(ss * inv_d - mean * mean, 0.f);
+    *reinterpret_cast<f32x2*>(stats + 2 * (long long)r) = f32x2{mean, rsqrtf(var + eps)};
+}
+
+// one wave per row, two-pass (mean, then centred sum of squares) like layernorm_kernel, no output row
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, int rows, int D, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 3;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            load8<T>(x + (long long)row * D + c * 8, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (long long)row) = f32x2{mean, rstd};
+}
+}  // namespace
+
+extern "C" int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream) {
+    AFHIP_CHECK(partials && stats && P > 0 && rows > 0 && D > 0, "afhip_ln_stats_finalize: bad args P=%d rows=%d D=%d", P, rows, D);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, partials, P, rows, 1.0f / (float)D, eps, stats);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int afhip_row_stats(const void* x, int rows, int D, float eps, int dtype, float* stats, void* stream) {
+    if (int e = check_row("afhip_row_stats", rows, D, dtype)) return e;
+    AFHIP_CHECK(x && stats, "afhip_row_stats: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(row_stats_kernel<bf16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const bf16*)x, rows, D, eps, stats),
+               hipLaunchKernelGGL(row_stats_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const float*)x, rows, D, eps, stats));
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+
 // Row gather of the AF3 / Qwen2-Audio placeholder merge (modeling_whisper.py:1056-1104): out row r is text row plan[r]
 // (plan >= 0), audio row -(plan[r] + 2) (plan <= -2) or zeros (plan == -1, padding).  One wave per row, 16 B per lane.
 namespace {

@@ -190,8 +190,25 @@ class AFWhisperEncoder(nn.Module):
             lists["fc1_b"].append(P(lyr.fc1.bias))
             lists["fc2_w"].append(P(lyr.fc2.weight))
             lists["fc2_b"].append(P(lyr.fc2.bias))
+        # bf16 throughput mode: LayerNorm-folded copies of the two projections that follow a LayerNorm (afhip.h,
+        # afhip_encoder_weights.qkv_wf ...): W' = W diag(gamma) rounded once to bf16, its f32 row sums (taken from the ROUNDED
+        # W', so the mean term cancels exactly what the MFMAs accumulate) and the f32 bias b + W beta.  AFHIP_LN_FOLD=0 keeps
+        # every LayerNorm as its own pass (A/B switch).
+        fold_names = []
+        if dt == torch.bfloat16 and os.environ.get("AFHIP_LN_FOLD", "1") != "0" and cfg.d_model % 256 == 0 and cfg.encoder_ffn_dim % 256 == 0:
+            fold_names = ["qkv_wf", "qkv_cs", "qkv_bf", "fc1_wf", "fc1_cs", "fc1_bf"]
+            for n in fold_names:
+                lists[n] = []
+            for i, lyr in enumerate(self.layers):
+                for pre, wt, bt, ln in (("qkv", lists["qkv_w"][i], lists["qkv_b"][i], lyr.self_attn_layer_norm),
+                                        ("fc1", lists["fc1_w"][i], lists["fc1_b"][i], lyr.final_layer_norm)):
+                    w32, g32, b32 = wt.float(), ln.weight.detach().float(), ln.bias.detach().float()
+                    wf = P((w32 * g32[None, :]).to(torch.bfloat16))
+                    lists[pre + "_wf"].append(wf)
+                    lists[pre + "_cs"].append(P(wf.float().sum(dim=1)))
+                    lists[pre + "_bf"].append(P(bt.float() + w32 @ b32))
         arrays = {}
-        for n in names:
+        for n in names + fold_names:
             arrays[n] = L.ptr_array(lists[n])
             setattr(w, n, C.cast(arrays[n], L.c_void_pp))
         w.lnf_w, w.lnf_b = P(self.layer_norm.weight).data_ptr(), P(self.layer_norm.bias).data_ptr()

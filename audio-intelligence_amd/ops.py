@@ -17,8 +17,10 @@ def _chk(t: torch.Tensor, name: str):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
          residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, out: Optional[torch.Tensor] = None,
-         conv: Optional[tuple] = None) -> torch.Tensor:
-    """C = epilogue(A @ W^T). a [M,K] (or x [B,Tin,C] with conv=(Tout, stride)), w [N,K]."""
+         conv: Optional[tuple] = None, ln_fold: Optional[tuple] = None, row_stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(A @ W^T). a [M,K] (or x [B,Tin,C] with conv=(Tout, stride)), w [N,K].
+    ln_fold = (stats [M,2] f32, colsum [N] f32, bias [N] f32): LayerNorm folded around the GEMM (afhip.h, afhip_gemm_args.ln_stats);
+    row_stats_out [N/64, M, 2] f32 receives the (sum, sum of squares) partials of the stored rows."""
     lib = L.lib()
     _chk(a, "gemm.a"), _chk(w, "gemm.w")
     dt = L.dtype_code(a.dtype)
@@ -47,8 +49,34 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     args.ldw, args.ldc = w.stride(0), out.stride(0)
     args.ldres = residual.stride(0) if residual is not None else 0
     args.dtype, args.act, args.res_row_mod = dt, act, res_row_mod
+    if ln_fold is not None:
+        st, cs, bf = ln_fold
+        assert st.dtype == cs.dtype == bf.dtype == torch.float32 and st.shape == (M, 2) and cs.shape == (N,) and bf.shape == (N,)
+        args.ln_stats, args.ln_colsum, args.ln_bias = st.data_ptr(), cs.data_ptr(), bf.data_ptr()
+    if row_stats_out is not None:
+        assert row_stats_out.dtype == torch.float32 and row_stats_out.is_contiguous() and row_stats_out.numel() >= (N // 64) * M * 2
+        args.row_stats_out = row_stats_out.data_ptr()
     L.check(lib.afhip_gemm(C.byref(args), L.stream_ptr()))
     return out
+
+
+def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """[rows, D] -> [rows, 2] f32 (mean, rsqrt(var + eps)): the LayerNorm statistics of the GEMM-folded form."""
+    lib = L.lib()
+    _chk(x, "row_stats.x")
+    assert x.dim() == 2 and x.is_contiguous()
+    st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    L.check(lib.afhip_row_stats(L.ptr(x), x.shape[0], x.shape[1], eps, L.dtype_code(x.dtype), L.ptr(st), L.stream_ptr()))
+    return st
+
+
+def ln_stats_finalize(partials: torch.Tensor, D: int, eps: float = 1e-5) -> torch.Tensor:
+    """[P, rows, 2] f32 (sum, sum of squares) partials -> [rows, 2] (mean, rstd)."""
+    lib = L.lib()
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.dim() == 3 and partials.shape[2] == 2
+    st = torch.empty((partials.shape[1], 2), dtype=torch.float32, device=partials.device)
+    L.check(lib.afhip_ln_stats_finalize(L.ptr(partials), partials.shape[0], partials.shape[1], D, eps, L.ptr(st), L.stream_ptr()))
+    return st
 
 
 def layernorm(x, w, b, eps: float = 1e-5):

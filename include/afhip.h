@@ -86,6 +86,17 @@ typedef struct {
      * M <= 32, K % 128 == 0): C = A' . (w_scale[n] * Wq[n,:])^T.  ACT_SWIGLU is accepted here as the epilogue of a
      * 32-row interleaved gate/up weight (N >= 8192), for both weight formats. */
     const float* w_scale; /* != NULL selects the fp8-weight kernel */
+    /* LayerNorm folded around the large bf16 GEMMs of the encoder layer (modeling_whisper.py:481-519): no normalised copy of
+     * the residual stream is ever written.  Consumer (q/k/v, fc1): A is the RAW stream x, W = W0 diag(gamma) and
+     *   C = rstd[m] * (x W^T - mean[m] * ln_colsum[n]) + ln_bias[n]   -> act,       ln_bias = b0 + W0 beta (f32)
+     * with ln_stats [M][2] = (mean, rstd) per row.  Producer (out-proj, fc2: bias + residual): row_stats_out
+     * [N/64][M][2] receives per-64-column partial (sum, sum of squares) of the rows it stores; afhip_ln_stats_finalize
+     * turns them into ln_stats.  Both need the ping-pong kernel's shape rules (bf16, N % 256 == 0, K % 128 == 0,
+     * M >= 512); afhip_gemm fails otherwise. */
+    const float* ln_stats;
+    const float* ln_colsum;
+    const float* ln_bias;
+    float* row_stats_out;
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
@@ -115,6 +126,11 @@ int afhip_gemm_skinny(const afhip_gemm_args* args, void* stream);
 int afhip_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, int dtype, void* stream);
 int afhip_avgpool_ln(const void* x, const void* w, const void* b, void* y, int B, int Tout, int D, float eps, int dtype, void* stream);
 int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float eps, int dtype, void* stream);
+/* LayerNorm statistics for the folded form above.  finalize: partials [P][rows][2] (sum, sum of squares over D/P columns
+ * each) -> stats [rows][2] = (mean, rsqrt(var + eps)), var = E[x^2] - mean^2 in f32.  row_stats: the same from the rows
+ * themselves (first layer, whose input comes from the conv stem). */
+int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream);
+int afhip_row_stats(const void* x, int rows, int D, float eps, int dtype, float* stats, void* stream);
 /* Row gather of the AF3 / Qwen2-Audio placeholder merge: replaces the three index_put / masked assignments of
  * Qwen2AudioForConditionalGeneration._merge_input_ids_with_audio_features (modeling_whisper.py:1056-1104).
  * plan [n_rows] int32 (device): >= 0 text row index into text_rows [n_text_rows, row_bytes]; <= -2 audio row -(v + 2) of
@@ -179,6 +195,12 @@ typedef struct {
     const void* const* fc1_w; const void* const* fc1_b;
     const void* const* fc2_w; const void* const* fc2_b;
     const void* lnf_w; const void* lnf_b;
+    /* optional, bf16 only (all six or none; NULL = every LayerNorm is its own pass): LayerNorm-folded copies of the two
+     * projections that follow a LayerNorm, built once by the host (AFWhisperEncoder.pack()):
+     *   qkv_wf [3d,d] = qkv_w diag(ln1_w) (bf16), qkv_cs [3d] = row sums of qkv_wf (f32), qkv_bf [3d] = qkv_b + qkv_w ln1_b (f32)
+     *   fc1_wf [ffn,d], fc1_cs [ffn], fc1_bf [ffn] likewise with ln2.  See afhip_gemm_args.ln_stats. */
+    const void* const* qkv_wf; const float* const* qkv_cs; const float* const* qkv_bf;
+    const void* const* fc1_wf; const float* const* fc1_cs; const float* const* fc1_bf;
 } afhip_encoder_weights;
 size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 /* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);

@@ -514,3 +514,50 @@ def test_attention_software_pipelined_opt_in():
             assert float((out - ref).abs().max()) <= (0.06 if spike else 0.02), f"attention_pp B={B} T={T} lens={lens}"
     finally:
         os.environ.pop("AFHIP_ATTN_PP", None)
+
+
+def test_gemm_layernorm_folded_forms():
+    """LayerNorm folded around the ping-pong GEMM (afhip_gemm_args.ln_stats / row_stats_out, modeling_whisper.py:481-519):
+    consumer  LN(x) W^T + b  ==  rstd (x W'^T - mean colsum) + (b + W beta)   and producer row statistics of the stored rows."""
+    from audio_intelligence_amd import ops, _lib as L
+    dt = torch.bfloat16
+    M, d, N = 1500, 1280, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, d, generator=g) * 1.7 + torch.randn(M, 1, generator=g) * 0.8 + 0.3     # rows with non-zero mean
+    x[:, 7] += 25.0                                                                             # an outlier channel, as Whisper streams have
+    gamma = 1.0 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    W = torch.randn(N, d, generator=g) * 0.03
+    b = 0.1 * torch.randn(N, generator=g)
+    xd, xf = _q(x, dt)
+    Wq = W.to(dt)
+    wf = (Wq.float() * gamma.to(dt).float()[None, :]).to(dt)
+    cs = wf.float().sum(1)
+    bf = b.to(dt).float() + Wq.float() @ beta.to(dt).float()
+    st = ops.row_stats(xd)
+    mu, var = xf.mean(1), xf.var(1, unbiased=False)
+    assert float((st[:, 0].cpu() - mu).abs().max()) <= 1e-5 * float(mu.abs().max() + 1)
+    assert float((st[:, 1].cpu() * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 1e-5
+    for act in (L.ACT_NONE, L.ACT_GELU):
+        y = ops.gemm(xd, wf.to(_dev()), act=act, ln_fold=(st, cs.to(_dev()), bf.to(_dev())))
+        ln = F.layer_norm(xf.double(), (d,), gamma.to(dt).double(), beta.to(dt).double(), 1e-5)
+        ref = ln @ Wq.double().T + b.to(dt).double()
+        if act == L.ACT_GELU:
+            ref = F.gelu(ref)
+        # same tolerance as the unfolded bf16 path (LN -> bf16 -> GEMM), which this replaces
+        _check(y, ref.float(), 3e-2, 3e-2, f"LN-folded gemm act={act}")
+        y_unf = ops.gemm(ops.layernorm(xd, gamma.to(dt).to(_dev()), beta.to(dt).to(_dev())), Wq.to(_dev()), bias=b.to(dt).to(_dev()), act=act)
+        e_f = float((y.float().cpu() - ref.float()).abs().mean()); e_u = float((y_unf.float().cpu() - ref.float()).abs().mean())
+        assert e_f <= 1.5 * e_u + 1e-4, f"folded form less accurate than LayerNorm + GEMM: {e_f} vs {e_u}"
+    # producer: statistics of the rows it stores (bias + residual epilogue), merged by the finalize kernel
+    K2 = 256
+    ad, af = _q(_rand(M, K2, seed=301), dt)
+    w2d, w2f = _q(_rand(d, K2, seed=302, scale=0.05), dt)
+    b2d, b2f = _q(_rand(d, seed=303, scale=0.1), dt)
+    rd, rf = _q(_rand(M, d, seed=304), dt)
+    part = torch.zeros(d // 64, M, 2, dtype=torch.float32, device=_dev())
+    out = ops.gemm(ad, w2d, bias=b2d, residual=rd, row_stats_out=part)
+    st2 = ops.ln_stats_finalize(part, d).cpu()
+    of = out.float().cpu()
+    assert float((st2[:, 0] - of.mean(1)).abs().max()) <= 1e-5
+    assert float((st2[:, 1] * torch.sqrt(of.var(1, unbiased=False) + 1e-5) - 1).abs().max()) <= 1e-4
