@@ -79,7 +79,8 @@ __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const fl
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < KCMAX; ++k) acc = fmaf(wk[k], pv[k], acc);   // same left-to-right order as the reference's band sum
-        const float v = log10f(fmaxf(acc, 1e-10f));
+        // log10 = log2 * log10(2) on v_log_f32 (1 ulp; the argument is >= 1e-10, far from the denormal range)
+        const float v = __builtin_amdgcn_logf(fmaxf(acc, 1e-10f)) * 0.30102999566398120f;
         scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
         mx = fmaxf(mx, v);
     }
@@ -294,11 +295,11 @@ __device__ __forceinline__ void dft5(float& r0, float& i0, float& r1, float& i1,
     r3 = a2r - b2i; i3 = a2i + b2r;
 }
 
-__global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
+__global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
                                                         const float* __restrict__ tab, float* __restrict__ scratch,
                                                         int* __restrict__ clipmax, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-#define LM_STAMP(k) do { if (dbg && blockIdx.x == 40 && blockIdx.y == 0 && threadIdx.x == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LM_STAMP(k) do { if (dbg && blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
     LM_STAMP(0);
     float* xs = reinterpret_cast<float*>(smem_raw);          // [FFT_ROWS][FFT_PITCH] samples, later [FFT_FT][FFT_PROW] power
     float* tw = xs + FFT_MAIN;                               // [200][2] e^{-2 pi i j / 200}
@@ -307,50 +308,74 @@ __global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restri
     int* cband = reinterpret_cast<int*>(cw + Tables::CWMAX); // [NMEL][3] first bin, count, offset
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * FFT_FT;
+    constexpr int NTILE = (NFRAMES + FFT_FT - 1) / FFT_FT;
     const float* w = wav + (long long)b * wav_stride;
 
-    for (int i = tid; i < 400; i += 256) { tw[i] = tab[Tables::TW200 + i]; wn[i] = tab[Tables::WINF + i]; }
-    for (int i = tid; i < (int)Tables::CWMAX; i += 256) cw[i] = tab[Tables::CW + i];
-    for (int i = tid; i < NMEL; i += 256) {
-        const int* band_g = reinterpret_cast<const int*>(tab + Tables::BAND);
-        cband[3 * i] = band_g[2 * i];
-        cband[3 * i + 1] = band_g[2 * i + 1];
-        cband[3 * i + 2] = reinterpret_cast<const int*>(tab + Tables::COFF)[i];
+    // constant tables -> registers first (all global loads of the prologue are in flight together with the sample loads below;
+    // the LDS stores follow the last load issue): twiddles + window (800 floats), compact mel weights (512), band table
+    float tr[4], cr[2];
+    int br[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        tr[2 * u] = i < 400 ? tab[Tables::TW200 + i] : 0.f;
+        tr[2 * u + 1] = i < 400 ? tab[Tables::WINF + i] : 0.f;
+        cr[u] = tab[Tables::CW + i];
     }
-    // ---- stage samples (same conventions as the DFT form): padded index p = t0*160 + s, original i = p - 200 ----
+    if (tid < NMEL) {
+        const int* band_g = reinterpret_cast<const int*>(tab + Tables::BAND);
+        br[0] = band_g[2 * tid]; br[1] = band_g[2 * tid + 1]; br[2] = reinterpret_cast<const int*>(tab + Tables::COFF)[tid];
+    }
+    // ---- sample staging (same conventions as the DFT form): padded index p = t0*160 + s, original i = p - 200.  The workgroup
+    //      is PERSISTENT over frame tiles of its clip: the global loads of tile n+1 are issued before the FFT of tile n and
+    //      parked in registers (their HBM latency, ~3.5 us per tile when exposed, hides under the arithmetic) ----
     constexpr int NSTAGE = (FFT_FT - 1) * HOP + NFFT;       // 5360 samples = 1340 float4
     constexpr int NV4 = NSTAGE / 4, V4_PER_THREAD = (NV4 + 255) / 256;
-    const int ibase = t0 * HOP - NFFT / 2;
-    const bool interior = ibase >= 0 && ibase + NSTAGE <= n_samples && (n_samples <= NSAMP) && ((wav_stride & 3) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
     f32x4 sv[V4_PER_THREAD];
+    const bool vec_ok = (n_samples <= NSAMP) && ((wav_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
+    auto tile_interior = [&](int tile) __attribute__((always_inline)) {
+        const int ibase = tile * FFT_FT * HOP - NFFT / 2;
+        return vec_ok && ibase >= 0 && ibase + NSTAGE <= n_samples;
+    };
+    // interior tiles (neither clip edge nor zero-padded tail): aligned float4 loads into registers, stored to LDS later
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        const int ibase = tile * FFT_FT * HOP - NFFT / 2;
 #pragma unroll
-    for (int u = 0; u < V4_PER_THREAD; ++u) {
-        const int v = tid + 256 * u;
-        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (v < NV4) {
-            if (interior) {
-                sv[u] = *reinterpret_cast<const f32x4*>(w + ibase + 4 * v);
-            } else {
+        for (int u = 0; u < V4_PER_THREAD; ++u) {
+            const int v = tid + 256 * u;
+            if (v < NV4) sv[u] = *reinterpret_cast<const f32x4*>(w + ibase + 4 * v);
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int i = ibase + 4 * v + e;
-                    if (i < 0) i = -i;
-                    if (i >= NSAMP) i = 2 * (NSAMP - 1) - i;
-                    if (i >= 0 && i < n_samples) sv[u][e] = w[i];
-                }
+        for (int u = 0; u < V4_PER_THREAD; ++u) {
+            const int v = tid + 256 * u;
+            if (v < NV4) {
+                const int sidx = 4 * v;                          // 160 % 4 == 0: the 4 samples share a hop row
+                *reinterpret_cast<f32x4*>(xs + (sidx / HOP) * FFT_PITCH + (sidx % HOP)) = sv[u];
             }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < V4_PER_THREAD; ++u) {
-        const int v = tid + 256 * u;
-        if (v < NV4) {
-            const int sidx = 4 * v;                          // 160 % 4 == 0: the 4 samples share a hop row
-            *reinterpret_cast<f32x4*>(xs + (sidx / HOP) * FFT_PITCH + (sidx % HOP)) = sv[u];
+    };
+    // edge tiles (2-3 of the 94 of a full clip): reflect padding / zero tail element by element, straight to LDS, not prefetched
+    auto stage_edge_tile = [&](int tile) __attribute__((always_inline)) {
+        const int ibase = tile * FFT_FT * HOP - NFFT / 2;
+        for (int sidx = tid; sidx < NSTAGE; sidx += 256) {
+            int i = ibase + sidx;
+            if (i < 0) i = -i;
+            if (i >= NSAMP) i = 2 * (NSAMP - 1) - i;
+            xs[(sidx / HOP) * FFT_PITCH + (sidx % HOP)] = (i >= 0 && i < n_samples) ? w[i] : 0.f;
         }
+    };
+    const bool first_interior = tile_interior(blockIdx.x);
+    if (first_interior) load_tile(blockIdx.x);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        if (i < 400) { tw[i] = tr[2 * u]; wn[i] = tr[2 * u + 1]; }
+        cw[i] = cr[u];
     }
+    if (tid < NMEL) { cband[3 * tid] = br[0]; cband[3 * tid + 1] = br[1]; cband[3 * tid + 2] = br[2]; }
+    if (first_interior) store_tile(); else stage_edge_tile(blockIdx.x);
     __syncthreads();
 
     LM_STAMP(1);
@@ -365,12 +390,25 @@ __global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restri
     const int k1p = (8 - k1) & 7;
     const int src0 = (lane & ~7) | (((k1p & 1) << 2) | (k1p & 2) | ((k1p >> 2) & 1));   // lane holding Z[200 - 25 k1]
 
+    float mx = -INFINITY;
+    for (int tile = blockIdx.x; tile < NTILE; tile += gridDim.x) {
+    const int t0 = tile * FFT_FT;
+    const int next = tile + (int)gridDim.x;
+    const bool next_interior = next < NTILE && tile_interior(next);
+    if (next_interior) load_tile(next);                      // in flight during this tile's arithmetic
+    // the window, twiddle and W400 values are loop-invariant per lane: the 50 window values are left to be hoisted into
+    // registers for the life of the workgroup (2 waves per SIMD have the room), the twiddle table base and the W400 lane factor
+    // are hidden behind opaque moves so those 100 values are NOT hoisted too (256 VGPRs + scratch otherwise)
+    const float* wn_t = wn; const float* tw_t = tw;
+    asm volatile("" : "+v"(tw_t));
+    float lr_t = lr, li_t = li;                                 // likewise the 25 per-lane W400 products of the unpack
+    asm volatile("" : "+v"(lr_t), "+v"(li_t));
     // ---- load + window: z[m] = (x[16m + 2t], x[16m + 2t + 1]) . w ----
     float zr[25], zi[25];
 #pragma unroll
     for (int m = 0; m < 25; ++m) {
         const f32x2 xv = *reinterpret_cast<const f32x2*>(xs + (f + m / 10) * FFT_PITCH + 16 * (m % 10) + 2 * t);
-        const f32x2 wv = *reinterpret_cast<const f32x2*>(wn + 16 * m + 2 * t);
+        const f32x2 wv = *reinterpret_cast<const f32x2*>(wn_t + 16 * m + 2 * t);
         zr[m] = xv[0] * wv[0];
         zi[m] = xv[1] * wv[1];
     }
@@ -400,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restri
 #pragma unroll
         for (int kb = 0; kb < 5; ++kb) {
             const int q = ka + 5 * kb;
-            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw + 2 * (t * q));
+            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw_t + 2 * (t * q));
             const float ar = zr[5 * ka + kb], ai = zi[5 * ka + kb];
             yr[q] = ar * tv[0] - ai * tv[1];
             yi[q] = ar * tv[1] + ai * tv[0];
@@ -433,7 +471,7 @@ __global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restri
             else { pr = lane_xor7(yr[25 - q]); pi = lane_xor7(yi[25 - q]); }
             const float er = 0.5f * (yr[q] + pr), ei = 0.5f * (yi[q] - pi);
             const float o_r = 0.5f * (yi[q] + pi), o_i = -0.5f * (yr[q] - pr);
-            const float wr = W400R[q] * lr - W400I[q] * li, wi = W400R[q] * li + W400I[q] * lr;
+            const float wr = W400R[q] * lr_t - W400I[q] * li_t, wi = W400R[q] * li_t + W400I[q] * lr_t;
             const float xr = er + wr * o_r - wi * o_i, xi = ei + wr * o_i + wi * o_r;
             pw[q + 25 * k1] = xr * xr + xi * xi;
         }
@@ -443,8 +481,14 @@ __global__ __launch_bounds__(256, 3) void logmel_pass1_fft(const float* __restri
 
     // ---- banded mel + log10; scratch is [B][3000][128] f32 ----
     LM_STAMP(6);
-    float mx = mel_tail<FFT_FT, FFT_PROW>(xs, cw, cband, scratch, b, t0, tid);
+    mx = fmaxf(mx, mel_tail<FFT_FT, FFT_PROW>(xs, cw, cband, scratch, b, t0, tid));
     LM_STAMP(7);
+    if (next < NTILE) {
+        __syncthreads();                                     // the power tile has been consumed: LDS takes the next samples
+        if (next_interior) store_tile(); else stage_edge_tile(next);
+        __syncthreads();
+    }
+    }
     mx = wave_max(mx);
     if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
 }
@@ -555,7 +599,10 @@ extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_str
         const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL);
         const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
         unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
-        hipLaunchKernelGGL(logmel_pass1_fft, dim3(cdiv(NFRAMES, FFT_FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+        // persistent over frame tiles: 2 workgroups per CU in one generation (512 on 256 CUs; 2 waves per SIMD by registers), each walking ceil(94 / gx) tiles
+        int gx = cdiv(512, B);
+        gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);
+        hipLaunchKernelGGL(logmel_pass1_fft, dim3(gx, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
                            tables, scratch, clipmax, dbg);
     }
     const dim3 g2(cdiv(NFRAMES, 32), B);
