@@ -201,3 +201,33 @@ def test_fp8_decode_weights_track_bf16():
         n += 1
     print(f"fp8 decode: logits corr {corr:.4f}, greedy prefix match {n}/{len(ref)}")
     assert corr > 0.99 and n >= 1
+
+
+def test_driver_run_inference_matches_golden_and_isolates_errors(stack_f32, tmp_path):
+    """SURVEY 8f rows 1 + 3: checkpoint -> fresh model -> run_inference (scripts/inference.py:136-153, 270-304) reproduces the
+    reference's greedy token ids; a broken sample is reported and does not stop the shard."""
+    from audio_intelligence_amd import inference as inf
+    model, pre = stack_f32
+    g, _ = H.golden()
+    gold = g["llm_tiny"]["greedy_tokens"]
+    inf.save_checkpoint(model, str(tmp_path / "ck"))
+    fresh, pre2 = H.build_tiny_ualm(torch.float32, DEV)
+    with torch.no_grad():
+        for p_ in fresh.parameters():
+            p_.zero_()
+    inf.load_checkpoint(fresh, str(tmp_path / "ck"))
+    fresh.prepare_inference()
+    lcfg = H.tiny_llm()[0]
+    prompt = fc.make_prompt(lcfg["text_vocab"])
+    samples = [(("audio_to_caption", "synthetic", f"clip{i}"), {"audio": (fc.make_wav(1000 + i, 160000)[None], 16000), "text": [["user", "text", prompt]]})
+               for i in range(2)]
+    samples.insert(1, (("audio_to_caption", "synthetic", "broken"), {"audio": (np.zeros((1, 16000), np.float32), 8000), "text": [["user", "text", prompt]]}))
+    seen = []
+    res = inf.run_inference(fresh, pre2, samples, CFG, device=DEV, dtype=torch.float32, enforce_modality="text",
+                            on_result=lambda i, k, r: seen.append(k))
+    assert seen == ["clip0", "broken", "clip1"]
+    assert "error" in res["broken"]                                   # 8 kHz audio: the caller must resample (INTEGRATION.md)
+    for i in range(2):
+        role, modality, ids = res[f"clip{i}"][0]
+        assert role == "assistant" and modality == "text"
+        assert [row[0] for row in ids] == gold[i], f"clip {i}"

@@ -164,3 +164,43 @@ def test_merge_refuses_cpu():
     with pytest.raises(L.AfhipError):
         merge(torch.zeros(1, 2, 8), torch.tensor([2]), torch.zeros(1, 3, 8), torch.tensor([[1, 99, 2]]), torch.ones(1, 3, dtype=torch.long),
               audio_token_index=99)
+
+
+def test_checkpoint_roundtrip_and_errors(tmp_path):
+    """DeepSpeed `mp_rank_00_model_states.pt`["module"] ingestion (scripts/inference.py:136-153)."""
+    import torch
+    from audio_intelligence_amd import inference as inf
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+    ecfg, esd = H.tiny_enc()
+    enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(ecfg))
+    enc.load_state_dict(esd)
+    path = inf.save_checkpoint(enc, str(tmp_path / "ckpt"), tag="global_step7")
+    assert path.endswith("global_step7/mp_rank_00_model_states.pt")
+    enc2 = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(ecfg))
+    for p in enc2.parameters():
+        torch.nn.init.zeros_(p)
+    inf.load_checkpoint(enc2, str(tmp_path / "ckpt"))                      # via the `latest` tag file
+    for k, v in enc.state_dict().items():
+        assert torch.equal(v, enc2.state_dict()[k]), k
+    inf.load_checkpoint(enc2, path)                                         # the file itself
+    inf.load_checkpoint(enc2, str(tmp_path / "ckpt" / "global_step7"))      # the tag directory
+    torch.save({"not_module": {}}, str(tmp_path / "bad.pt"))
+    with pytest.raises(KeyError):
+        inf.load_checkpoint(enc2, str(tmp_path / "bad.pt"))
+    sd = {k: v for k, v in enc.state_dict().items() if not k.startswith("conv1")}
+    torch.save({"module": sd}, str(tmp_path / "short.pt"))
+    with pytest.raises(RuntimeError):                                        # strict=True, as the reference
+        inf.load_checkpoint(enc2, str(tmp_path / "short.pt"))
+    with pytest.raises(FileNotFoundError):
+        inf.load_checkpoint(enc2, str(tmp_path / "nowhere"))
+
+
+def test_to_device_casts_floats_only():
+    """utils/data.py:93-130: floats take the model dtype, integer tensors keep theirs, containers are walked."""
+    import torch
+    from audio_intelligence_amd import inference as inf
+    d = {"seqs": torch.zeros(1, 3, 8, dtype=torch.long), "feats": [torch.zeros(2, 2), np.zeros((2,), np.float32)], "keys": [("a", "b", "c")],
+         "n": 3}
+    o = inf.to_device(d, "cpu", dtype=torch.bfloat16)
+    assert o["seqs"].dtype == torch.long and o["feats"][0].dtype == torch.bfloat16 and o["feats"][1].dtype == torch.bfloat16
+    assert o["keys"] == [("a", "b", "c")] and o["n"] == 3
