@@ -37,7 +37,8 @@ class AttnArgs(C.Structure):
                 ("q_batch_stride", C.c_longlong), ("kv_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
                 ("q_head_stride", C.c_longlong), ("kv_head_stride", C.c_longlong),
                 ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
-                ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t)]
+                ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
+                ("q_prescaled", C.c_int)]
 
 
 class EncoderWeights(C.Structure):
@@ -50,7 +51,7 @@ class EncoderWeights(C.Structure):
                 ("fc1_w", c_void_pp), ("fc1_b", c_void_pp), ("fc2_w", c_void_pp), ("fc2_b", c_void_pp),
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p),
                 ("qkv_wf", c_void_pp), ("qkv_cs", c_void_pp), ("qkv_bf", c_void_pp),
-                ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp)]
+                ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp), ("q_prescaled", C.c_int)]
 
 
 class LlmWeights(C.Structure):

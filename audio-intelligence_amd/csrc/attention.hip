@@ -384,7 +384,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.q_bs = a->q_batch_stride; p.kv_bs = a->kv_batch_stride; p.o_bs = a->o_batch_stride;
     p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride; p.o_hs = a->o_head_stride > 0 ? a->o_head_stride : a->hd;
     p.causal = a->causal; p.q_pos0 = a->q_pos0;
-    p.scale_log2 = a->scale * 1.4426950408889634f;
+    p.scale_log2 = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     // key-range splitting for tiny query counts (decode): partials + a combine pass
     int n_split = 1;

@@ -306,8 +306,10 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(AttnPP p) {
 }  // namespace
 
 bool attn_pp_eligible(const afhip_attn_args* a) {
-    // OPT-IN (AFHIP_ATTN_PP=1): measured 0.52-0.53 ms per encoder layer against 0.54 ms for attention.hip, not enough to
-    // pay for the extra bf16 rounding of the pre-scaled Q (max |err| 2.3e-3 vs 1.1e-3 on N(0,1) inputs); see DESIGN.md
+    // OPT-IN (AFHIP_ATTN_PP=1).  Alone it runs 0.52 ms per encoder layer against 0.54 ms for attention.hip; inside the full
+    // encoder step (same box, back to back) it is 0.5 ms per step SLOWER, so attention.hip stays the default.  With
+    // q_prescaled (scale folded into the q projection, as the LayerNorm-folded encoder does) it costs no accuracy; on plain q
+    // it adds a second bf16 rounding of q (max |err| 2.3e-3 vs 1.1e-3 on N(0,1) inputs).
     const char* e = getenv("AFHIP_ATTN_PP");
     if (!(e && e[0] == '1')) return false;
     if (a->dtype != AFHIP_BF16 || a->hd != 64 || a->causal || a->key_split > 0) return false;
@@ -324,7 +326,7 @@ int attn_pp_launch(const afhip_attn_args* a, hipStream_t s) {
     p.ld_q = a->ld_q; p.ld_kv = a->ld_kv; p.ld_o = a->ld_o;
     p.q_bs = a->q_batch_stride; p.kv_bs = a->kv_batch_stride; p.o_bs = a->o_batch_stride;
     p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride; p.o_hs = a->o_head_stride > 0 ? a->o_head_stride : a->hd;
-    p.scale_log2 = a->scale * 1.4426950408889634f;
+    p.scale_log2 = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f;
     p.n_xt = cdiv(a->Tq, APP_QT);
     AFHIP_CHECK((long long)p.n_xt * a->n_q * a->B < (1ll << 31), "afhip_attention: grid too large");
     static bool attr_done = false;

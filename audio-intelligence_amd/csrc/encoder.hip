@@ -111,6 +111,7 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         a.q_head_stride = hd; a.kv_head_stride = hd;
         a.o_head_stride = 0; a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         a.causal = 0; a.q_pos0 = 0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        a.q_prescaled = (fold && w->q_prescaled) ? 1 : 0;
         if (fold) {
             if (l == 0 && (rc = afhip_row_stats(ws.h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
             if ((rc = gemm(ws.h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,

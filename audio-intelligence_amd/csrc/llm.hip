@@ -203,7 +203,7 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
         a.hd = hd; a.ld_kv = hd;
         a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.kv_head_stride = (long long)cache->cap * hd;
-        a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
+        a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt; a.q_prescaled = 0;
         a.B = B; a.Tk = pos0 + T;
         const int rep = nq / nkv;
         if (T == 1 && rep <= 32) {

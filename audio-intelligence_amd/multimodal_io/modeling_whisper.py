@@ -203,10 +203,16 @@ class AFWhisperEncoder(nn.Module):
                 for pre, wt, bt, ln in (("qkv", lists["qkv_w"][i], lists["qkv_b"][i], lyr.self_attn_layer_norm),
                                         ("fc1", lists["fc1_w"][i], lists["fc1_b"][i], lyr.final_layer_norm)):
                     w32, g32, b32 = wt.float(), ln.weight.detach().float(), ln.bias.detach().float()
-                    wf = P((w32 * g32[None, :]).to(torch.bfloat16))
+                    rs = torch.ones(w32.shape[0], device=w32.device)
+                    if pre == "qkv":
+                        # the softmax scale in exp2 units rides on the q rows too (afhip_attn_args.q_prescaled): scores leave the
+                        # q.k MFMA ready for exp2, and q is rounded to bf16 once, after the scale
+                        rs[: cfg.d_model] = (cfg.d_model // cfg.encoder_attention_heads) ** -0.5 * 1.4426950408889634
+                    wf = P((w32 * g32[None, :] * rs[:, None]).to(torch.bfloat16))
                     lists[pre + "_wf"].append(wf)
                     lists[pre + "_cs"].append(P(wf.float().sum(dim=1)))
-                    lists[pre + "_bf"].append(P(bt.float() + w32 @ b32))
+                    lists[pre + "_bf"].append(P((bt.float() + w32 @ b32) * rs))
+        w.q_prescaled = 1 if fold_names else 0
         arrays = {}
         for n in names + fold_names:
             arrays[n] = L.ptr_array(lists[n])

@@ -172,6 +172,9 @@ typedef struct {
                                   the partial softmaxes in a second pass: for decode-size query counts (Tq <= 32, causal 0) */
     void* partial_ws;          /* f32 scratch, ceil(Tk/key_split) * B * n_q * 32 * (hd + 2) * 4 bytes */
     size_t partial_ws_bytes;
+    int q_prescaled;           /* != 0: q already carries scale * log2(e) (folded into the q projection by the caller, one rounding);
+                                * `scale` is ignored and exp2 is taken of the raw scores.  Lets the software-pipelined kernel
+                                * (attention_pp.hip) run without its own second rounding of q. */
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 
@@ -201,6 +204,7 @@ typedef struct {
      *   fc1_wf [ffn,d], fc1_cs [ffn], fc1_bf [ffn] likewise with ln2.  See afhip_gemm_args.ln_stats. */
     const void* const* qkv_wf; const float* const* qkv_cs; const float* const* qkv_bf;
     const void* const* fc1_wf; const float* const* fc1_cs; const float* const* fc1_bf;
+    int q_prescaled;  /* != 0: the q rows of qkv_wf / qkv_cs / qkv_bf also carry head_dim^-0.5 * log2(e) (softmax scale in exp2 units) */
 } afhip_encoder_weights;
 size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 /* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);
