@@ -16,6 +16,13 @@
 // gate/up block pair, so the K-slice combine emits silu(gate) * up straight into the [M, N/2] activation (modeling_qwen2.py:46-48).
 #include "common.h"
 
+#ifndef SKINNY_DEPTH
+#define SKINNY_DEPTH 2      /* K steps in flight per wave, NT >= 2 (3 costs the second workgroup per CU: measured slower) */
+#endif
+#ifndef SKINNY_DEPTH1
+#define SKINNY_DEPTH1 2     /* the same for the narrow NT = 1 tiles */
+#endif
+
 namespace {
 
 enum { A_PLAIN = 0, A_RMSNORM = 1, A_SWIGLU = 2 };
@@ -164,19 +171,30 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
             }
     };
 
-    // two steps of loads in flight per wave
-    int s = wave;
-    for (; s + 8 < nsteps; s += 16) {
-        StepRegs<NT, MT> r0, r1;
-        issue(s, r0);
-        issue(s + 8, r1);
-        consume(r0);
-        consume(r1);
-    }
-    if (s < nsteps) {
-        StepRegs<NT, MT> r0;
-        issue(s, r0);
-        consume(r0);
+    // rolling window of two steps per wave: a register set is re-issued right after it is consumed, so the wave never
+    // drains to zero loads in flight (issue-two / consume-two exposed one full HBM round trip per pair of steps; with
+    // K = 3584 a wave only has 7 steps).  Steps are still consumed in ascending order: sums are bit-identical.
+    {
+        constexpr int DEPTH = NT == 1 ? SKINNY_DEPTH1 : SKINNY_DEPTH;   // register sets = K steps in flight per wave
+        StepRegs<NT, MT> r[DEPTH];
+        int sx[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            sx[d] = wave + 8 * d;
+            if (sx[d] < nsteps) issue(sx[d], r[d]);
+        }
+        bool more = sx[0] < nsteps;
+        while (more) {
+            more = false;
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (sx[d] < nsteps) {
+                    consume(r[d]);
+                    sx[d] += 8 * DEPTH;
+                    if (sx[d] < nsteps) { issue(sx[d], r[d]); more = true; }
+                }
+            }
+        }
     }
 
     // ---- combine the 8 K-slices through LDS ----

@@ -8,6 +8,13 @@
 // Reference counterpart: none (BASELINE config 5 "fp8 MFMA GEMMs"); checked against the dequantised weights in f32.
 #include "common.h"
 
+#ifndef SKINNY_DEPTH
+#define SKINNY_DEPTH 2      /* K steps in flight per wave, NT >= 2 (3 costs the second workgroup per CU: measured slower) */
+#endif
+#ifndef SKINNY_DEPTH1
+#define SKINNY_DEPTH1 2     /* the same for the narrow NT = 1 tiles */
+#endif
+
 namespace {
 
 enum { A_PLAIN = 0, A_RMSNORM = 1 };
@@ -133,18 +140,28 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
         }
     };
 
-    int s = wave;
-    for (; s + 8 < nsteps; s += 16) {
-        StepRegs8<NT, MT> r0, r1;
-        issue(s, r0);
-        issue(s + 8, r1);
-        consume(r0);
-        consume(r1);
-    }
-    if (s < nsteps) {
-        StepRegs8<NT, MT> r0;
-        issue(s, r0);
-        consume(r0);
+    // rolling window of two steps per wave (see gemm_skinny.hip): a register set is re-issued as soon as it is consumed
+    {
+        constexpr int DEPTH = NT == 1 ? SKINNY_DEPTH1 : SKINNY_DEPTH;   // register sets = K steps in flight per wave
+        StepRegs8<NT, MT> r[DEPTH];
+        int sx[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            sx[d] = wave + 8 * d;
+            if (sx[d] < nsteps) issue(sx[d], r[d]);
+        }
+        bool more = sx[0] < nsteps;
+        while (more) {
+            more = false;
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (sx[d] < nsteps) {
+                    consume(r[d]);
+                    sx[d] += 8 * DEPTH;
+                    if (sx[d] < nsteps) { issue(sx[d], r[d]); more = true; }
+                }
+            }
+        }
     }
 
 #pragma unroll

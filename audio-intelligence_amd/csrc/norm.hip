@@ -235,12 +235,22 @@ extern "C" int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, in
 
 // ---- LayerNorm statistics for the GEMM-folded form (afhip.h: afhip_gemm_args.ln_stats) ----
 namespace {
-__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int rows, float inv_d, float eps,
-                                                                float* __restrict__ stats) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int rows, float inv_d, float eps,
+                                                               float* __restrict__ stats) {
+    // one wave per 64 rows (750 workgroups for the encoder's 48000 rows: every CU gets some), partial loads unrolled by 4 so
+    // several are in flight per lane
+    const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
     float s = 0.f, ss = 0.f;
-    for (int p = 0; p < P; ++p) {
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+        f32x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x2*>(part + 2 * ((long long)(p + u) * rows + r));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += v[u][0]; ss += v[u][1]; }
+    }
+    for (; p < P; ++p) {
         const f32x2 v = *reinterpret_cast<const f32x2*>(part + 2 * ((long long)p * rows + r));
         s += v[0]; ss += v[1];
     }
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x,
 
 extern "C" int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream) {
     AFHIP_CHECK(partials && stats && P > 0 && rows > 0 && D > 0, "afhip_ln_stats_finalize: bad args P=%d rows=%d D=%d", P, rows, D);
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, partials, P, rows, 1.0f / (float)D, eps, stats);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, partials, P, rows, 1.0f / (float)D, eps, stats);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }
