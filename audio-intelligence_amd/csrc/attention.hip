@@ -31,6 +31,7 @@ struct AttnP {
     int key_split;          // > 0: the x-tile index enumerates key ranges of this many keys (Tq <= 32), partials go to part_o / part_ml
     float* part_o;          // [split][B][n_q][32][HD] unnormalised O^T columns
     float* part_ml;         // [split][B][n_q][32][2]  running max (raw score units) and sum
+    unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -171,7 +172,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
     __syncthreads();
 
+#ifdef AFHIP_ATTN_STAMPS   /* diagnostic build: -DAFHIP_ATTN_STAMPS, tools/attn_stamps.py */
+#define AT_STAMP(k) do { if (p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 3) && lane == 0 && t >= 8 && t < 12) p.dbg[((wave ? 1 : 0) * 4 + (t - 8)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AT_STAMP(k) do { } while (0)
+#endif
     for (int t = tbeg; t < ntiles; ++t) {
+        AT_STAMP(0);
         const int k0 = t * KT;
         const int cur = NBUF == 2 ? ((t - tbeg) & 1) : 0;
         Ks = smem + cur * STAGE_BYTES;
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
 
+        AT_STAMP(1);
         // ---- online softmax (query = this lane's column).  Masking is compiled into boundary tiles only (wave-uniform
         //      branch): interior tiles run max / fma / exp2 / add per score and nothing else. ----
         const bool edge = (k0 + KT > klen) || (p.causal && (k0 + KT - 1 > wave_qpos_min));
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         l_i += psum;
 
+        AT_STAMP(2);
         // ---- O^T += V^T . P^T ; step s covers keys [16s, 16s+16) of the tile ----
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -274,9 +283,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
 
+        AT_STAMP(3);
         if constexpr (NBUF == 2) {
             if (t + 1 < ntiles) store_tile(cur ^ 1);   // the other stage: its last readers passed the previous barrier
+            AT_STAMP(4);
             __syncthreads();
+            AT_STAMP(5);
         } else {
             __syncthreads();
             if (t + 1 < ntiles) store_tile(0);
@@ -389,6 +401,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     // key-range splitting for tiny query counts (decode): partials + a combine pass
     int n_split = 1;
     p.key_split = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    { const char* dp = getenv("AFHIP_ATTN_DBGPTR"); p.dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr; }
     if (a->key_split > 0) {
         AFHIP_CHECK(a->key_split % KT == 0, "afhip_attention: key_split must be a multiple of %d", KT);
         AFHIP_CHECK(a->Tq <= 32 && !a->causal, "afhip_attention: key_split needs Tq <= 32 and causal == 0");

@@ -101,17 +101,20 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(AttnPP p) {
     const unsigned ldkv2 = (unsigned)(p.ld_kv * 2);
     const unsigned kv_bytes = (unsigned)(p.Tk - 1) * ldkv2 + 128u;
     char* const dma_dst = smem + wave * 1024;
+    // row byte offset of key (t * 64 + drow), clamped to the last key: one multiply here, adds afterwards
+    const int row_last = (p.Tk - 1) * (int)ldkv2, tile_step = APP_KT * (int)ldkv2;
+    const int row0 = drow * (int)ldkv2;
     auto dma_k = [&](int t) __attribute__((always_inline)) {
-        int key = t * APP_KT + drow;
-        key = key < p.Tk ? key : p.Tk - 1;
+        int off = row0 + t * tile_step;
+        off = off < row_last ? off : row_last;
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)kv_bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dma_dst + (t & (APP_NS - 1)) * APP_TILE), 16, key * (int)ldkv2 + kchunk * 16, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dma_dst + (t & (APP_NS - 1)) * APP_TILE), 16, off + kchunk * 16, 0, 0, 0);
     };
     auto dma_v = [&](int t) __attribute__((always_inline)) {
-        int key = t * APP_KT + drow;
-        key = key < p.Tk ? key : p.Tk - 1;
+        int off = row0 + t * tile_step;
+        off = off < row_last ? off : row_last;
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)kv_bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dma_dst + (APP_NS + (t & (APP_NS - 1))) * APP_TILE), 16, key * (int)ldkv2 + vchunk * 16, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dma_dst + (APP_NS + (t & (APP_NS - 1))) * APP_TILE), 16, off + vchunk * 16, 0, 0, 0);
     };
 
     // ---- fragment read maps (attention.hip) ----
@@ -191,7 +194,13 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(AttnPP p) {
             mxd = fmaxf(fmaxf(mxd, st[1][8 + e]), st[1][9 + e]);
         }
         float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {
+            // lanes l and l ^ 32 hold the two halves of a query's keys: v_permlane32_swap (VALU, no LDS round trip) in inline asm,
+            // because the builtin called with two copies of one value is folded away by the compiler
+            float ma = mx, mb = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
+            mx = fmaxf(ma, mb);
+        }
         if (first || __any(mx > APP_THR)) {
             const float d = first ? mx : fmaxf(mx, 0.f);
             if (!first) {
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(AttnPP p) {
         read_v(j);
         mfma_qk(stn, false);
         exp_pack(st, pfc);
-        if constexpr (DBG == 0) {
+        if constexpr (DBG == 1) {   // explicit MFMA : LDS : VALU interleave pattern -- measured 8-10 % SLOWER than the compiler's own order
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads (the 16 transposed V reads)
-                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // 9 VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU (an MFMA leaves 24 of its 32 cycles to the issue port)
             }
         }
         stamp(j, 3);

@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restri
                                                         const float* __restrict__ tab, float* __restrict__ scratch,
                                                         int* __restrict__ clipmax, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef AFHIP_LOGMEL_STAMPS   /* diagnostic build: -DAFHIP_LOGMEL_STAMPS, tools/mel_stamps.py */
 #define LM_STAMP(k) do { if (dbg && blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LM_STAMP(k) do { } while (0)
+#endif
     LM_STAMP(0);
     float* xs = reinterpret_cast<float*>(smem_raw);          // [FFT_ROWS][FFT_PITCH] samples, later [FFT_FT][FFT_PROW] power
     float* tw = xs + FFT_MAIN;                               // [200][2] e^{-2 pi i j / 200}
