@@ -34,6 +34,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef PP_SETPRIO
+#define PP_SETPRIO 1   /* s_setprio(1) around each MFMA cluster (keeps hipcc from moving MFMAs across the barriers, cdna guide T5) */
+#endif
+
 namespace {
 
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
@@ -194,7 +198,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         constexpr int HA = decltype(ha_tag)::value, HB = decltype(hb_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#if PP_SETPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -202,7 +208,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
+#if PP_SETPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto read_a = [&](const char* half) {
 #pragma unroll
