@@ -30,6 +30,11 @@
 // the residual loads) are 16 B per lane straight from registers, 64 contiguous bytes per row per instruction.
 // LDS image: 128-B rows, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7) (conflict-free ds_read_b128); the DMA
 // writes linearly, so the swizzle is applied to its per-lane SOURCE chunk.
+//
+// Epilogues (template flags): + bias, erf-GELU, + residual (all 16 loads of a lane issued before the math), SwiGLU pair
+// (32-row interleaved gate/up weights -> C [M, N/2]), and the two halves of the LayerNorm fold (afhip.h,
+// afhip_gemm_args.ln_stats): LNFOLD applies rstd[m] (acc - mean[m] colsum[n]) + bias'[n] on a GEMM over the raw residual
+// stream, STATS emits per-row (sum, sum of squares) partials of the rows it stores for the next LayerNorm.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
