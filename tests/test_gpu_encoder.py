@@ -211,3 +211,31 @@ def test_long_audio_window_path_single_gpu():
     mask = (torch.arange(3000)[None, :] < (n_valid // 160)[:, None]).long()[:, None, :]
     ref = oracle.afwhisper.sound_tower(mel, mask, sd, cfg)
     assert _maxerr(out, ref) <= 3e-4
+
+
+def test_full_size_batch_consistency_bf16():
+    """BASELINE configs[1] at its full size (B = 32 x 30 s, 32 layers, d 1280, bf16): a size-independent property instead of a
+    CPU reference.  Every row's arithmetic (K order of the GEMM tiles, key order of the attention tiles, LayerNorm statistics)
+    is independent of where the row sits in the batch, so (a) 32 copies of one clip give 32 bit-identical outputs, (b) they are
+    bit-identical to the B = 2 run that test_full_shape_encoder_against_reference_golden pins to the reference's values, and
+    (c) a batch of distinct clips equals the same clips encoded one by one."""
+    _need_gpu()
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+    from audio_intelligence_amd.utils import synthetic as syn
+    cfg = oracle.afwhisper.default_config()
+    enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(cfg))
+    enc.load_state_dict(syn.synth_state_dict(syn.encoder_param_shapes(cfg), fc.SEED_ENC_FULL), strict=True)
+    enc = enc.to(DEV, torch.bfloat16)
+    mel = torch.from_numpy(H.mel_of(2000, 480000))[None].transpose(1, 2).contiguous().to(DEV)
+    out2 = enc.encode_btc(torch.cat([mel, mel]))
+    out32 = enc.encode_btc(mel.expand(32, -1, -1).contiguous())
+    assert list(out32.shape) == [32, 750, 1280]
+    for b in range(32):
+        assert torch.equal(out32[b], out32[0]), f"row {b} of the batch differs from row 0"
+    assert torch.equal(out32[0], out2[0])
+    g = torch.Generator().manual_seed(11)
+    mels = torch.randn(5, 3000, 128, generator=g).mul_(0.3).to(DEV)
+    batch = enc.encode_btc(torch.cat([mels, mel.expand(27, -1, -1)]).contiguous())
+    for b in range(5):
+        single = enc.encode_btc(torch.cat([mels[b:b + 1], mel]).contiguous())      # B = 2: same kernels as the batch
+        assert torch.equal(batch[b], single[0]), f"clip {b}: batched != alone"
