@@ -19,6 +19,9 @@
 #ifndef SKINNY_DEPTH
 #define SKINNY_DEPTH 2      /* K steps in flight per wave, NT >= 2 (3 costs the second workgroup per CU: measured slower) */
 #endif
+#ifndef SKINNY_NW1
+#define SKINNY_NW1 8        /* waves per workgroup for the narrow bf16 tiles; 16 measured the same (3.79 vs 3.78 ms per 7B step): those launches are at the launch floor, not chain-bound */
+#endif
 #ifndef SKINNY_DEPTH1
 #define SKINNY_DEPTH1 2     /* the same for the narrow NT = 1 tiles */
 #endif
@@ -70,14 +73,14 @@ template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
 
 template <int NT, int MT> struct StepRegs { u32x4 w0[NT], w1[NT], a0[MT], a1[MT], x0[MT], x1[MT], n0, n1; };
 
-template <typename T, int NT, int MT, int AMODE>
-__global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
+template <typename T, int NT, int MT, int AMODE, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     constexpr int SZ = sizeof(T);
     constexpr int KS = Step<T>::K;
     constexpr int HN = Half<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NT][MT][64 lanes][4]
-    float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16] row sums of squares (A_RMSNORM)
+    float* red_ss = red + NW * NT * MT * 256;                      // [8 waves][MT][16] row sums of squares (A_RMSNORM)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
         int sx[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            sx[d] = wave + 8 * d;
+            sx[d] = wave + NW * d;
             if (sx[d] < nsteps) issue(sx[d], r[d]);
         }
         bool more = sx[0] < nsteps;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
             for (int d = 0; d < DEPTH; ++d) {
                 if (sx[d] < nsteps) {
                     consume(r[d]);
-                    sx[d] += 8 * DEPTH;
+                    sx[d] += NW * DEPTH;
                     if (sx[d] < nsteps) { issue(sx[d], r[d]); more = true; }
                 }
             }
@@ -218,12 +221,12 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
         if (p.swiglu_out) {
             // first NT/2 tiles = gate rows, last NT/2 tiles = the matching up rows (32 further in W); C is [M, N/2]
             constexpr int NG = NT / 2;
-            for (int o = tid; o < NG * MT * 256; o += 512) {
+            for (int o = tid; o < NG * MT * 256; o += NW * 64) {
                 const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
                 const int mt = tile % MT, nt = tile / MT;        // gate tile
                 float g = 0.f, u = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
+                for (int w = 0; w < NW; ++w) {
                     g += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
                     u += red[((((w * NT + nt + NG) * MT + mt) * 64 + ln) << 2) + reg];
                 }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
                     if constexpr (AMODE == A_RMSNORM) {
                         float sq = 0.f;
 #pragma unroll
-                        for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                        for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
                         const float r = rsqrtf(sq / (float)p.K + p.norm_eps);
                         g *= r; u *= r;
                     }
@@ -245,12 +248,12 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
             return;
         }
     }
-    for (int o = tid; o < NT * MT * 256; o += 512) {
+    for (int o = tid; o < NT * MT * 256; o += NW * 64) {
         const int reg = o & 3, ln = (o >> 2) & 63, tile = o >> 8;
         const int mt = tile % MT, nt = tile / MT;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
+        for (int w = 0; w < NW; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
         const int n = n_base + nt * 16 + (ln & 15);
         const int mrow = 4 * (ln >> 4) + reg;
         const int m = mt * 16 + mrow;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
             if constexpr (AMODE == A_RMSNORM) {
                 float sq = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
                 v *= rsqrtf(sq / (float)p.K + p.norm_eps);
             }
             if (p.bias) v += to_f32<T>(reinterpret_cast<const T*>(p.bias)[n]);
@@ -269,14 +272,18 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyP p) {
     }
 }
 
+// NW = waves that split K inside a workgroup.  The narrow bf16 tiles (NT = 1: q/k/v and o of the decoder, 224-288 workgroups of
+// 7 K steps per wave) can split K over 16 waves (SKINNY_NW1); f32 always keeps 8 (its summation order is part of
+// the bit-exact parity contract).
 template <typename T, int NT, int MT>
 void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
-    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(512);
-    const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
+    constexpr int NW = (NT == 1 && sizeof(T) == 2 && MT <= 2) ? SKINNY_NW1 : 8;
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(NW * 64);
+    const size_t lds = ((size_t)NW * NT * MT * 256 + NW * MT * 16) * sizeof(float);
     switch (amode) {
-        case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM>), grid, block, lds, s, p); break;
-        case A_SWIGLU: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_SWIGLU>), grid, block, lds, s, p); break;
-        default: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_PLAIN>), grid, block, lds, s, p); break;
+        case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM, NW>), grid, block, lds, s, p); break;
+        case A_SWIGLU: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_SWIGLU, NW>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_PLAIN, NW>), grid, block, lds, s, p); break;
     }
 }
 
