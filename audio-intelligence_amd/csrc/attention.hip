@@ -31,6 +31,11 @@ struct AttnP {
     int key_split;          // > 0: the x-tile index enumerates key ranges of this many keys (Tq <= 32), partials go to part_o / part_ml
     float* part_o;          // [split][B][n_q][32][HD] unnormalised O^T columns
     float* part_ml;         // [split][B][n_q][32][2]  running max (raw score units) and sum
+    const char* new_k;      // decode: fused RoPE + KV append (afhip.h); NULL = off
+    const char* new_v;
+    long long new_kv_bs;
+    const float* rope_cos;
+    const float* rope_sin;
     unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
 };
 
@@ -119,6 +124,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         const T* qp = reinterpret_cast<const T*>(qb) + (long long)qrow_c * p.ld_q;
 #pragma unroll
         for (int dc = 0; dc < DSTEPS; ++dc) qf[dc] = *reinterpret_cast<const typename Frag8<T>::type*>(qp + dc * 16 + fh * 8);
+        if (p.new_k) {
+            // fused RoPE (decode): element d = dc*16 + fh*8 + e pairs with d + HD/2, i.e. step dc + DSTEPS/2 of the SAME lane.
+            // q cos + rotate_half(q) sin with separate roundings, then the storage dtype -- exactly rope_kv_kernel (norm.hip)
+#pragma unroll
+            for (int dc = 0; dc < DSTEPS / 2; ++dc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = dc * 16 + fh * 8 + e;
+                    const float c = p.rope_cos[i], sn = p.rope_sin[i];
+                    const float x1 = to_f32<T>(qf[dc][e]), x2 = to_f32<T>(qf[dc + DSTEPS / 2][e]);
+                    qf[dc][e] = from_f32<T>(rope_mad(x1, c, -x2, sn));
+                    qf[dc + DSTEPS / 2][e] = from_f32<T>(rope_mad(x2, c, x1, sn));
+                }
+        }
     }
 
     f32x16 ot[DT];
@@ -140,6 +159,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             const long long off = ((long long)key * p.ld_kv) * SZ + cc * 16;
             rk[i] = ld16(kb + off);
             rv[i] = ld16(vb + off);
+            if (p.new_k && k0 + row == p.Tk - 1) {
+                // fused KV append (decode): this chunk of the token being generated comes from the projection output, not from
+                // the cache; k is rotated here (partner elements d +- HD/2 sit KCPR/2 chunks away in the same row), and both are
+                // written to the cache for the following steps.  Only the workgroup whose key range holds Tk-1 gets here.
+                const char* nk = p.new_k + ((long long)b * p.new_kv_bs + (long long)hkv * HD) * SZ;
+                const char* nv = p.new_v + ((long long)b * p.new_kv_bs + (long long)hkv * HD) * SZ;
+                const bool lo = cc < KCPR / 2;
+                const u32x4 own = ld16(nk + cc * 16), par = ld16(nk + (cc ^ (KCPR / 2)) * 16);
+                const int i0 = (lo ? cc : cc - KCPR / 2) * EPC;
+                T ov[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float c = p.rope_cos[i0 + e], sn = p.rope_sin[i0 + e];
+                    const float xo = to_f32<T>(reinterpret_cast<const T*>(&own)[e]), xp = to_f32<T>(reinterpret_cast<const T*>(&par)[e]);
+                    // first half: x1 = own, x2 = partner -> x1 c - x2 s;  second half: x2 = own, x1 = partner -> x2 c + x1 s
+                    ov[e] = from_f32<T>(lo ? rope_mad(xo, c, -xp, sn) : rope_mad(xo, c, xp, sn));
+                }
+                rk[i] = *reinterpret_cast<const u32x4*>(ov);
+                rv[i] = ld16(nv + cc * 16);
+                st16(const_cast<char*>(kb) + off, rk[i]);
+                st16(const_cast<char*>(vb) + off, rv[i]);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -401,6 +442,12 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     // key-range splitting for tiny query counts (decode): partials + a combine pass
     int n_split = 1;
     p.key_split = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    p.new_k = (const char*)a->new_k; p.new_v = (const char*)a->new_v; p.new_kv_bs = a->new_kv_batch_stride;
+    p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+    if (a->new_k) {
+        AFHIP_CHECK(a->key_split > 0 && a->new_v && a->rope_cos && a->rope_sin, "afhip_attention: fused RoPE/append needs key_split > 0, new_v and the cos/sin rows");
+        AFHIP_CHECK(((uintptr_t)a->new_k % 16) == 0 && ((uintptr_t)a->new_v % 16) == 0 && (a->new_kv_batch_stride * sz) % 16 == 0, "afhip_attention: new_k / new_v must keep 16-byte alignment");
+    }
     { const char* dp = getenv("AFHIP_ATTN_DBGPTR"); p.dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr; }
     if (a->key_split > 0) {
         AFHIP_CHECK(a->key_split % KT == 0, "afhip_attention: key_split must be a multiple of %d", KT);

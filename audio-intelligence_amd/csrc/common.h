@@ -98,4 +98,14 @@ __device__ __forceinline__ float erf_as(float x) {
 template <typename T> __device__ __forceinline__ float gelu_act(float x);
 template <> __device__ __forceinline__ float gelu_act<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_act<bf16>(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// a*ca + b*sb with THREE roundings (two products, one sum), never contracted into an FMA: the rotate-half RoPE of
+// modeling_qwen2.py:133-134 (q * cos + rotate_half(q) * sin as separate tensor ops).  __fmul_rn / __fadd_rn are plain
+// operators in HIP and -ffp-contract=fast fuses them (v_fma_f32 in the f32 kernels), which is 1 ulp away from the reference
+// and differs between code sites; every RoPE in the library goes through this helper so they agree bit for bit.
+__device__ __forceinline__ float rope_mad(float a, float ca, float b, float sb) {
+#pragma clang fp contract(off)
+    const float p0 = a * ca;
+    const float p1 = b * sb;
+    return p0 + p1;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

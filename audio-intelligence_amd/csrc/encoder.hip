@@ -8,6 +8,8 @@
 //   tail : AvgPool1d(2,2) + LayerNorm fused
 #include "common.h"
 
+bool gemm_pp_available();   // gemm_pp.hip
+
 namespace {
 
 struct EncWs {
@@ -99,10 +101,10 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
     // stream.  out-proj / fc2 emit row (sum, sum of squares) partials of what they store, a 3-us finalize turns them into
     // (mean, rstd), and q/k/v / fc1 run on the RAW stream with gamma folded into their weights (afhip.h).
     const bool fold = dt == AFHIP_BF16 && w->qkv_wf && w->qkv_cs && w->qkv_bf && w->fc1_wf && w->fc1_cs && w->fc1_bf &&
-                      rows >= 512 && d % 256 == 0 && f % 256 == 0;
+                      rows >= 512 && d % 256 == 0 && f % 256 == 0 && gemm_pp_available();
     const int P = d / 64;
     for (int l = 0; l < w->n_layers; ++l) {
-        afhip_attn_args a;
+        afhip_attn_args a = {};
         a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = ws.att;
         a.key_len = feat_len;
         a.B = B; a.Tq = Tp; a.Tk = Tp; a.n_q = w->n_heads; a.n_kv = w->n_heads; a.hd = hd;

@@ -431,6 +431,9 @@ void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
 
 }  // namespace
 
+// false when the A/B switch AFHIP_GEMM_PP=0 is set: callers that would use the LayerNorm-folded forms must not (encoder.hip)
+bool gemm_pp_available() { return pp_enabled(); }
+
 // Shapes the ping-pong kernel takes: bf16 in / bf16 out, no implicit conv, whole 256-column tiles,
 // an even number of 64-deep K tiles, 16-byte aligned rows everywhere, operands addressable with 32-bit byte offsets.
 bool gemm_pp_eligible(const afhip_gemm_args* a) {

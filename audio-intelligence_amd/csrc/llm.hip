@@ -201,15 +201,17 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
             if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
             if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         }
-        if ((rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
-        afhip_attn_args a;
+        const int rep = nq / nkv;
+        const bool decode_attn = T == 1 && rep <= 32;
+        // decode: RoPE and the cache append ride inside the attention launch (afhip_attn_args.new_k); prefill: their own pass
+        if (!decode_attn && (rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
+        afhip_attn_args a = {};
         a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
         a.hd = hd; a.ld_kv = hd;
         a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.kv_head_stride = (long long)cache->cap * hd;
         a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt; a.q_prescaled = 0;
         a.B = B; a.Tk = pos0 + T;
-        const int rep = nq / nkv;
-        if (T == 1 && rep <= 32) {
+        if (decode_attn) {
             // decode: the `rep` query heads that share a kv head are the query rows of one workgroup, so each K/V byte is
             // streamed once per group; the context is split into DECODE_KEY_SPLIT-key ranges over workgroups and merged (flash-decoding)
             a.Tq = rep; a.n_q = nkv; a.n_kv = nkv;
@@ -217,6 +219,8 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
             a.ld_o = hd; a.o_head_stride = (long long)rep * hd; a.o_batch_stride = (long long)nq * hd;
             a.causal = 0; a.q_pos0 = 0;
             a.key_split = DECODE_KEY_SPLIT; a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
+            a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
+            a.rope_cos = w->rope_cos + (size_t)pos0 * (hd / 2); a.rope_sin = w->rope_sin + (size_t)pos0 * (hd / 2);
         } else {
             a.Tq = T; a.n_q = nq; a.n_kv = nkv;
             a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;

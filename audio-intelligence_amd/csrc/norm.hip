@@ -151,8 +151,8 @@ __global__ void rope_kv_kernel(T* __restrict__ qkv, int ld, const float* __restr
         const float c = cosT[(long long)pos * half + i], s = sinT[(long long)pos * half + i];
         const float x1 = to_f32<T>(src[i]), x2 = to_f32<T>(src[i + half]);
         // q*cos + rotate_half(q)*sin with separate roundings (modeling_qwen2.py:133-134)
-        const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, s));
-        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+        const float o1 = rope_mad(x1, c, -x2, s);
+        const float o2 = rope_mad(x2, c, x1, s);
         if (head < n_q) {
             src[i] = from_f32<T>(o1);
             src[i + half] = from_f32<T>(o2);

@@ -209,10 +209,12 @@ def rope_kv(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, 
 
 
 def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int, tk: int,
-                     key_split: int = 256, ld_q: Optional[int] = None):
+                     key_split: int = 256, ld_q: Optional[int] = None, fused_rope: Optional[tuple] = None):
     """One new token per sequence: q [B, >= n_q*hd] (row stride ld_q) against the first `tk` positions of a KV cache
     [B,n_kv,cap,hd].  The q heads of a kv group become the query rows of one workgroup and the context is split into
-    `key_split`-key ranges merged by a second pass (flash-decoding)."""
+    `key_split`-key ranges merged by a second pass (flash-decoding).
+    fused_rope = (qkv [B, (n_q + 2 n_kv) * hd] un-rotated projection output (q is its first n_q*hd columns), cos [hd/2], sin [hd/2]
+    f32 rows of position tk-1): RoPE on q and k and the append of k, v at cache position tk-1 happen inside the launch."""
     lib = L.lib()
     _chk(q, "attention_decode.q")
     B = q.shape[0]
@@ -232,5 +234,12 @@ def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     a.q_head_stride, a.kv_head_stride, a.o_head_stride = rep * hd, cap * hd, rep * hd
     a.causal, a.q_pos0, a.scale, a.dtype = 0, 0, 1.0 / math.sqrt(hd), L.dtype_code(q.dtype)
     a.key_split, a.partial_ws, a.partial_ws_bytes = key_split, part.data_ptr(), part.numel() * 4
+    if fused_rope is not None:
+        qkv, cos, sin = fused_rope
+        assert qkv.is_contiguous() and cos.dtype == sin.dtype == torch.float32 and cos.numel() == hd // 2
+        sz = qkv.element_size()
+        a.new_k, a.new_v = qkv.data_ptr() + n_q * hd * sz, qkv.data_ptr() + (n_q + n_kv) * hd * sz
+        a.new_kv_batch_stride = qkv.stride(0)
+        a.rope_cos, a.rope_sin = cos.data_ptr(), sin.data_ptr()
     L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
     return out

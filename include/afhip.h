@@ -175,6 +175,17 @@ typedef struct {
     int q_prescaled;           /* != 0: q already carries scale * log2(e) (folded into the q projection by the caller, one rounding);
                                 * `scale` is ignored and exp2 is taken of the raw scores.  Lets the software-pipelined kernel
                                 * (attention_pp.hip) run without its own second rounding of q. */
+    /* Decode only (key_split > 0): rotate-half RoPE and the KV-cache append folded into this launch, so a decode step needs no
+     * afhip_rope_kv pass.  new_k != NULL switches it on: q rows are rotated as they are loaded (cos/sin rows of the token's
+     * position); the workgroup whose key range holds position Tk-1 reads the token's un-rotated k and its v from
+     * new_k / new_v (+ b * new_kv_batch_stride + kv_head * hd elements), rotates k, writes both into k / v (the cache) at
+     * position Tk-1 and uses them in place of the stale cache row.  Arithmetic identical to afhip_rope_kv
+     * (modeling_qwen2.py:105-136: separate roundings of the two products and the sum, then the storage dtype). */
+    const void* new_k;
+    const void* new_v;
+    long long new_kv_batch_stride;
+    const float* rope_cos; /* [hd/2] f32 of the position being appended */
+    const float* rope_sin;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 

@@ -561,3 +561,29 @@ def test_gemm_layernorm_folded_forms():
     of = out.float().cpu()
     assert float((st2[:, 0] - of.mean(1)).abs().max()) <= 1e-5
     assert float((st2[:, 1] * torch.sqrt(of.var(1, unbiased=False) + 1e-5) - 1).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nq,nkv,hd,tk", [(28, 4, 128, 801), (12, 2, 64, 300), (8, 8, 64, 65), (12, 2, 64, 1)])
+def test_attention_decode_fused_rope_append_is_bit_identical(dt, nq, nkv, hd, tk):
+    """Decode attention with RoPE + KV append folded into the launch (afhip_attn_args.new_k) against the two-launch form
+    (afhip_rope_kv, then afhip_attention): outputs AND the cache rows written must be bit-identical in both dtypes."""
+    from audio_intelligence_amd import ops
+    B, cap, pos = 3, 1024, tk - 1
+    qw = (nq + 2 * nkv) * hd
+    qkv, _ = _q(_rand(B, 1, qw, seed=71), dt)
+    kc0, _ = _q(_rand(B, nkv, cap, hd, seed=72), dt)
+    vc0, _ = _q(_rand(B, nkv, cap, hd, seed=73), dt)
+    inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.arange(cap).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous().to(_dev()), ang.sin().contiguous().to(_dev())
+    # reference: separate launches
+    q_a, kc_a, vc_a = qkv.clone(), kc0.clone(), vc0.clone()
+    ops.rope_kv(q_a, cos, sin, pos, kc_a, vc_a, nq, nkv)
+    out_a = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=128, ld_q=qw)
+    # fused
+    q_b, kc_b, vc_b = qkv.clone().reshape(B, qw), kc0.clone(), vc0.clone()
+    out_b = ops.attention_decode(q_b, kc_b, vc_b, nq, nkv, tk, key_split=128, ld_q=qw, fused_rope=(q_b, cos[pos].contiguous(), sin[pos].contiguous()))
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    assert torch.equal(q_b, qkv.reshape(B, qw))          # the fused form leaves the projection output untouched
