@@ -39,7 +39,7 @@ class AttnArgs(C.Structure):
                 ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
                 ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
                 ("q_prescaled", C.c_int), ("new_k", C.c_void_p), ("new_v", C.c_void_p), ("new_kv_batch_stride", C.c_longlong),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p)]
 
 
 class EncoderWeights(C.Structure):

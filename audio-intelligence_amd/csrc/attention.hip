@@ -36,6 +36,7 @@ struct AttnP {
     long long new_kv_bs;
     const float* rope_cos;
     const float* rope_sin;
+    int* ticket;            // split mode: in-launch merge by the last-arriving key-range workgroup (afhip.h); NULL = separate pass
     unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
 };
 
@@ -352,6 +353,41 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 }
             if (fh == 0) { p.part_ml[slot * 2] = m_i; p.part_ml[slot * 2 + 1] = l_tot; }
         }
+        if (p.ticket == nullptr) return;
+        // ---- in-launch merge (cdna guide, Guideline 16 counter form): publish, take a ticket, the last arriver merges ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's partial stores have left
+        __syncthreads();                                                   // ... and every wave's
+        int* flag = reinterpret_cast<int*>(smem);                          // the K/V tiles are dead: their LDS carries the verdict
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // keep: ROCm 7.2 can drop the fence's own wait
+            const int tk = __hip_atomic_fetch_add(p.ticket + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = (tk == p.n_xt - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (flag[0] == 0) return;                                          // wave-uniform
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // same arithmetic, same order over the key ranges as attn_combine_kernel
+        for (int idx = tid; idx < p.Tq * HD; idx += 256) {
+            const int qr = idx / HD, d = idx - qr * HD;
+            float m = -INFINITY;
+            for (int sp = 0; sp < p.n_xt; ++sp) m = fmaxf(m, p.part_ml[((((long long)sp * p.B + b) * p.n_q + hq) * 32 + qr) * 2]);
+            float l = 0.f, o = 0.f;
+            for (int sp = 0; sp < p.n_xt; ++sp) {
+                const long long slot = (((long long)sp * p.B + b) * p.n_q + hq) * 32 + qr;
+                const float ms = p.part_ml[slot * 2];
+                const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
+                l += p.part_ml[slot * 2 + 1] * w;
+                o += p.part_o[slot * HD + d] * w;
+            }
+            T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qr * p.ld_o + (long long)hq * p.o_hs;
+            op[d] = from_f32<T>(l > 0.f ? o / l : 0.f);
+        }
+        if (tid == 0) p.ticket[hb] = 0;                                    // ready for the next launch (ordered by the kernel boundary)
         return;
     }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -444,6 +480,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.key_split = 0; p.part_o = nullptr; p.part_ml = nullptr;
     p.new_k = (const char*)a->new_k; p.new_v = (const char*)a->new_v; p.new_kv_bs = a->new_kv_batch_stride;
     p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+    p.ticket = a->key_split > 0 ? a->split_ticket : nullptr;
     if (a->new_k) {
         AFHIP_CHECK(a->key_split > 0 && a->new_v && a->rope_cos && a->rope_sin, "afhip_attention: fused RoPE/append needs key_split > 0, new_v and the cos/sin rows");
         AFHIP_CHECK(((uintptr_t)a->new_k % 16) == 0 && ((uintptr_t)a->new_v % 16) == 0 && (a->new_kv_batch_stride * sz) % 16 == 0, "afhip_attention: new_k / new_v must keep 16-byte alignment");
@@ -487,7 +524,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     }
 #undef AFHIP_ATTN_LAUNCH
     AFHIP_LAUNCH_CHECK();
-    if (a->key_split > 0) {
+    if (a->key_split > 0 && a->split_ticket == nullptr) {
         const dim3 g2(a->B * a->n_q * a->Tq), b2(a->hd);
         if (a->dtype == AFHIP_BF16) hipLaunchKernelGGL(attn_combine_kernel<bf16>, g2, b2, 0, s, p, n_split, a->hd);
         else hipLaunchKernelGGL(attn_combine_kernel<float>, g2, b2, 0, s, p, n_split, a->hd);

@@ -7,6 +7,9 @@
 namespace {
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+#ifndef DECODE_IN_LAUNCH_MERGE
+#define DECODE_IN_LAUNCH_MERGE 0   /* 1: merge the decode attention's key-range partials by a last-arriver ticket instead of a second launch */
+#endif
 #ifndef DECODE_KEY_SPLIT
 #define DECODE_KEY_SPLIT 128   /* keys per workgroup of the split-context decode attention (multiple of 64); 256 / 128 / 64 measured 3.85 / 3.79 / 3.84 ms per 7B step */
 #endif
@@ -20,6 +23,8 @@ struct LlmWs {
     char* act2;  // [rows, inter]
     char* part;  // decode attention partials (T == 1)
     size_t part_bytes;
+    int* ticket; // [n_layers][rows * n_kv] arrival counters of the in-launch merge, zeroed once per decode step
+    size_t ticket_bytes;
     size_t total;
 };
 
@@ -38,6 +43,8 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
     // decode partials: ceil(ctx/DECODE_KEY_SPLIT) splits x rows(B) x n_kv x 32 x (hd+2) f32 (only used when T == 1)
     ws.part_bytes = max_ctx > 0 ? (size_t)((max_ctx + DECODE_KEY_SPLIT - 1) / DECODE_KEY_SPLIT) * rows * w->n_kv * 32 * (w->hd + 2) * sizeof(float) : 0;
     ws.part = take(ws.part_bytes);
+    ws.ticket_bytes = max_ctx > 0 ? (size_t)w->n_layers * rows * w->n_kv * sizeof(int) : 0;
+    ws.ticket = (int*)take(ws.ticket_bytes);
     ws.total = off;
     return ws;
 }
@@ -189,6 +196,7 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
     const size_t layer_kv = (size_t)cache->B * nkv * cache->cap * hd * sz;
     int rc;
     if (hipMemcpyAsync(ws.x, x, (size_t)rows * H * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("llm: input copy failed"); return AFHIP_ERR_LAUNCH; }
+    if (DECODE_IN_LAUNCH_MERGE && T == 1 && ws.ticket_bytes > 0 && hipMemsetAsync(ws.ticket, 0, ws.ticket_bytes, s) != hipSuccess) { afhip_set_error("llm: ticket memset failed"); return AFHIP_ERR_LAUNCH; }
 
     for (int l = 0; l < w->n_layers; ++l) {
         char* kc = (char*)cache->k + (size_t)l * layer_kv;
@@ -221,6 +229,9 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
             a.key_split = DECODE_KEY_SPLIT; a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
             a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
             a.rope_cos = w->rope_cos + (size_t)pos0 * (hd / 2); a.rope_sin = w->rope_sin + (size_t)pos0 * (hd / 2);
+            // the in-launch merge (a.split_ticket = ws.ticket + l * B * nkv) is correct and bit-identical but SLOWER here: 4.10 vs 3.76 ms
+            // per 7B step -- 224 workgroups each paying an agent-scope release (L2 write-back) cost more than one 5-us combine launch
+            a.split_ticket = DECODE_IN_LAUNCH_MERGE ? ws.ticket + (size_t)l * B * nkv : nullptr;
         } else {
             a.Tq = T; a.n_q = nq; a.n_kv = nkv;
             a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;

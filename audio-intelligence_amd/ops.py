@@ -209,12 +209,13 @@ def rope_kv(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, 
 
 
 def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int, tk: int,
-                     key_split: int = 256, ld_q: Optional[int] = None, fused_rope: Optional[tuple] = None):
+                     key_split: int = 256, ld_q: Optional[int] = None, fused_rope: Optional[tuple] = None, in_launch_merge: bool = False):
     """One new token per sequence: q [B, >= n_q*hd] (row stride ld_q) against the first `tk` positions of a KV cache
     [B,n_kv,cap,hd].  The q heads of a kv group become the query rows of one workgroup and the context is split into
     `key_split`-key ranges merged by a second pass (flash-decoding).
     fused_rope = (qkv [B, (n_q + 2 n_kv) * hd] un-rotated projection output (q is its first n_q*hd columns), cos [hd/2], sin [hd/2]
-    f32 rows of position tk-1): RoPE on q and k and the append of k, v at cache position tk-1 happen inside the launch."""
+    f32 rows of position tk-1): RoPE on q and k and the append of k, v at cache position tk-1 happen inside the launch.
+    in_launch_merge: the key-range partials are merged by the last-arriving workgroup instead of a second pass."""
     lib = L.lib()
     _chk(q, "attention_decode.q")
     B = q.shape[0]
@@ -234,6 +235,9 @@ def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     a.q_head_stride, a.kv_head_stride, a.o_head_stride = rep * hd, cap * hd, rep * hd
     a.causal, a.q_pos0, a.scale, a.dtype = 0, 0, 1.0 / math.sqrt(hd), L.dtype_code(q.dtype)
     a.key_split, a.partial_ws, a.partial_ws_bytes = key_split, part.data_ptr(), part.numel() * 4
+    if in_launch_merge:
+        ticket = torch.zeros(B * n_kv, dtype=torch.int32, device=q.device)
+        a.split_ticket = ticket.data_ptr()
     if fused_rope is not None:
         qkv, cos, sin = fused_rope
         assert qkv.is_contiguous() and cos.dtype == sin.dtype == torch.float32 and cos.numel() == hd // 2

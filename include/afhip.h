@@ -186,6 +186,11 @@ typedef struct {
     long long new_kv_batch_stride;
     const float* rope_cos; /* [hd/2] f32 of the position being appended */
     const float* rope_sin;
+    /* key_split > 0 only: merge the partial softmaxes INSIDE this launch instead of a second pass.  split_ticket: B * n_q device
+     * ints, zero before the launch (the kernel leaves them zero again).  Every key-range workgroup publishes its partial
+     * (stores -> s_waitcnt vmcnt(0) -> barrier -> agent-scope release -> relaxed agent atomic add); the workgroup that draws the
+     * last ticket acquires and merges all ranges in the same order as the second pass would: bit-identical output. */
+    int* split_ticket;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 

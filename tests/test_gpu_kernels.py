@@ -587,3 +587,12 @@ def test_attention_decode_fused_rope_append_is_bit_identical(dt, nq, nkv, hd, tk
     assert torch.equal(out_a, out_b)
     assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
     assert torch.equal(q_b, qkv.reshape(B, qw))          # the fused form leaves the projection output untouched
+    # ... and with the partial softmaxes merged inside the launch (last-arriver ticket) instead of by a second pass
+    kc_c, vc_c = kc0.clone(), vc0.clone()
+    for rep_ in range(3):                                  # repeated launches: the ticket must come back to zero
+        out_c = ops.attention_decode(q_b, kc_c, vc_c, nq, nkv, tk, key_split=128, ld_q=qw, fused_rope=(q_b, cos[pos].contiguous(), sin[pos].contiguous()),
+                                     in_launch_merge=True)
+        assert torch.equal(out_a, out_c), f"in-launch merge differs (launch {rep_})"
+    out_d = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw, in_launch_merge=True)
+    out_e = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw)
+    assert torch.equal(out_d, out_e)
