@@ -126,6 +126,17 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds_dst + 8192), 16, voff1, soff, 0, 0);
 }
 
+#ifndef PP_DMA_IN_MFMA
+#define PP_DMA_IN_MFMA 0   /* 1: a phase's half-tile DMA is issued inside its MFMA section (measured 5-7 % SLOWER: the DMA issue stalls the wave's own MFMA stream); 0: in its LOAD section (8-phase template) */
+#endif
+// counted wait of the LOAD sections of phases 3, 0, 1: the half-tile read in the NEXT phase has landed, younger ones stay in flight.
+// DMA in the LOAD section: issued so far includes this phase's -> 4 half-tiles (8 instructions) younger; DMA in the MFMA section:
+// this phase's is not issued yet -> 3 half-tiles (6 instructions) younger.
+#if PP_DMA_IN_MFMA
+#define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#else
+#define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#endif
 #define PP_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define PP_BARRIER()                              \
     do {                                          \
@@ -199,7 +210,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     PP_BARRIER();
     if (grp == 1) PP_BARRIER();                   // stagger: group 1 runs one barrier behind group 0
 
-    auto mfma_quad = [&](auto ha_tag, auto hb_tag, bf16x8 (&fbx)[2][2]) {
+    // 16 MFMAs of one quadrant; with PP_DMA_IN_MFMA the phase's LDS-DMA half-tile is issued between the two K halves, in the
+    // issue slots the wave's own MFMAs leave free (an MFMA holds the port 8 of its 16 cycles), instead of lengthening the LOAD
+    // section its partner's matrix pipe waits on
+    auto mfma_quad = [&](auto ha_tag, auto hb_tag, bf16x8 (&fbx)[2][2], auto&& dma) {
         constexpr int HA = decltype(ha_tag)::value, HB = decltype(hb_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -207,12 +221,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
+#if PP_DMA_IN_MFMA
+            if (kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
 #if PP_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -240,33 +262,45 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         const char* st = smem + S * PP_STAGE;
         char* d_same = dma_dst + S * PP_STAGE;
         char* d_other = dma_dst + (S ^ 1) * PP_STAGE;
+        auto dma0 = [&]() { pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], d_other + PP_OFF_B1); };
+        auto dma1 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
+        auto dma2 = [&]() { pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0); };
+        auto dma3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0); };
         // phase 0
         read_b(st + PP_OFF_B0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(st + PP_OFF_A0);
-        pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], d_other + PP_OFF_B1);
-        PP_WAIT_VM8();
+#if !PP_DMA_IN_MFMA
+        dma0();
+#endif
+        PP_WAIT_VM();
         PP_BARRIER();
-        mfma_quad(I0{}, I0{}, fb0);
+        mfma_quad(I0{}, I0{}, fb0, dma0);
         PP_BARRIER();
         // phase 1
         read_b(st + PP_OFF_B1, fb1);
-        pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1);
-        PP_WAIT_VM8();
+#if !PP_DMA_IN_MFMA
+        dma1();
+#endif
+        PP_WAIT_VM();
         PP_BARRIER();
-        mfma_quad(I0{}, I1{}, fb1);
+        mfma_quad(I0{}, I1{}, fb1, dma1);
         PP_BARRIER();
         // phase 2
         read_a(st + PP_OFF_A1);
-        pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0);
+#if !PP_DMA_IN_MFMA
+        dma2();
+#endif
         PP_BARRIER();
-        mfma_quad(I1{}, I1{}, fb1);
+        mfma_quad(I1{}, I1{}, fb1, dma2);
         PP_BARRIER();
         // phase 3
-        pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0);
-        PP_WAIT_VM8();
+#if !PP_DMA_IN_MFMA
+        dma3();
+#endif
+        PP_WAIT_VM();
         PP_BARRIER();
-        mfma_quad(I1{}, I0{}, fb0);
+        mfma_quad(I1{}, I0{}, fb0, dma3);
         PP_BARRIER();
         c1 = c2;
         pp_cur_advance(p, c2, n_my);
