@@ -126,6 +126,9 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds_dst + 8192), 16, voff1, soff, 0, 0);
 }
 
+#ifndef PP_VARIANT
+#define PP_VARIANT 2   /* tuning switches (0 / 1 / 2 / 3 measured on qkv: 1187 / 1140 / 1207 / 1170 TF): bit 0 = issue the DMA before the fragment reads of a LOAD section; bit 1 = no blanket lgkmcnt(0) in front of the MFMAs */
+#endif
 #ifndef PP_DMA_IN_MFMA
 #define PP_DMA_IN_MFMA 0   /* 1: a phase's half-tile DMA is issued inside its MFMA section (measured 5-7 % SLOWER: the DMA issue stalls the wave's own MFMA stream); 0: in its LOAD section (8-phase template) */
 #endif
@@ -215,8 +218,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     // section its partner's matrix pipe waits on
     auto mfma_quad = [&](auto ha_tag, auto hb_tag, bf16x8 (&fbx)[2][2], auto&& dma) {
         constexpr int HA = decltype(ha_tag)::value, HB = decltype(hb_tag)::value;
+#if !(PP_VARIANT & 2)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #if PP_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -267,10 +272,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         auto dma2 = [&]() { pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0); };
         auto dma3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0); };
         // phase 0
+#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
+        dma0();
+#endif
         read_b(st + PP_OFF_B0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(st + PP_OFF_A0);
-#if !PP_DMA_IN_MFMA
+#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma0();
 #endif
         PP_WAIT_VM();
@@ -278,8 +286,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         mfma_quad(I0{}, I0{}, fb0, dma0);
         PP_BARRIER();
         // phase 1
+#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
+        dma1();
+#endif
         read_b(st + PP_OFF_B1, fb1);
-#if !PP_DMA_IN_MFMA
+#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma1();
 #endif
         PP_WAIT_VM();
@@ -287,8 +298,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         mfma_quad(I0{}, I1{}, fb1, dma1);
         PP_BARRIER();
         // phase 2
+#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
+        dma2();
+#endif
         read_a(st + PP_OFF_A1);
-#if !PP_DMA_IN_MFMA
+#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma2();
 #endif
         PP_BARRIER();
