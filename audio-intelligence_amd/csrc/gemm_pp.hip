@@ -127,7 +127,7 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
 }
 
 #ifndef PP_VARIANT
-#define PP_VARIANT 2   /* tuning switches (0 / 1 / 2 / 3 measured on qkv: 1187 / 1140 / 1207 / 1170 TF): bit 0 = issue the DMA before the fragment reads of a LOAD section; bit 1 = no blanket lgkmcnt(0) in front of the MFMAs */
+#define PP_VARIANT 2   /* tuning switches (0 / 1 / 2 / 3 measured on qkv: 1187 / 1140 / 1207 / 1170 TF): bit 0 = issue the DMA before the fragment reads of a LOAD section; bit 1 = no blanket lgkmcnt(0) in front of the MFMAs; bit 2 = fragment reads tile-major instead of K-half-major */
 #endif
 #ifndef PP_DMA_IN_MFMA
 #define PP_DMA_IN_MFMA 0   /* 1: a phase's half-tile DMA is issued inside its MFMA section (measured 5-7 % SLOWER: the DMA issue stalls the wave's own MFMA stream); 0: in its LOAD section (8-phase template) */
@@ -244,19 +244,35 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
+    // fragment reads in the order the MFMAs consume them (K half 0 of every tile, then K half 1): with per-fragment lgkmcnt waits
+    // the first MFMAs start while the second half is still in flight
     auto read_a = [&](const char* half) {
+#if PP_VARIANT & 4
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = *reinterpret_cast<const bf16x8*>(half + aoff0 + i * 2048);
             fa[i][1] = *reinterpret_cast<const bf16x8*>(half + aoff1 + i * 2048);
         }
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][0] = *reinterpret_cast<const bf16x8*>(half + aoff0 + i * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(half + aoff1 + i * 2048);
+#endif
     };
     auto read_b = [&](const char* half, bf16x8 (&fbx)[2][2]) {
+#if PP_VARIANT & 4
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             fbx[j][0] = *reinterpret_cast<const bf16x8*>(half + boff0 + j * 2048);
             fbx[j][1] = *reinterpret_cast<const bf16x8*>(half + boff1 + j * 2048);
         }
+#else
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fbx[j][0] = *reinterpret_cast<const bf16x8*>(half + boff0 + j * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fbx[j][1] = *reinterpret_cast<const bf16x8*>(half + boff1 + j * 2048);
+#endif
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
