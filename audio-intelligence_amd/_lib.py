@@ -105,7 +105,8 @@ SIGNATURES = {
     "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I, _I]),
     "afhip_llm_forward": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
     "afhip_lm_head": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _P, _P, _Z, _P]),
-    "afhip_masked_argmax": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "afhip_masked_argmax_workspace_bytes": (_Z, [_I]),
+    "afhip_masked_argmax": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "afhip_llm_decode_step": (_I, [C.POINTER(LlmWeights), C.POINTER(KvCache), C.POINTER(DecodeState), _I, _I, _I, _P, _Z, _P]),
 }
 

@@ -338,13 +338,12 @@ int attn_pp_launch(const afhip_attn_args* a, hipStream_t s) {
     p.scale_log2 = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f;
     p.n_xt = cdiv(a->Tq, APP_QT);
     AFHIP_CHECK((long long)p.n_xt * a->n_q * a->B < (1ll << 31), "afhip_attention: grid too large");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    if (afhip_first_use_on_device(&attr_done)) {
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_LDS);
-        attr_done = true;
     }
     const char* de = getenv("AFHIP_ATTN_DBG");
     const int dbg = de ? atoi(de) : 0;

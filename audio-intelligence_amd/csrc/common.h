@@ -35,6 +35,14 @@ void afhip_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) is PER DEVICE: true the first time the calling site runs on the
+// current device of this thread, so a process that drives several GPUs sets the attribute on each of them.
+static inline bool afhip_first_use_on_device(unsigned long long* done_mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (__atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED) & bit) == 0;
+}
 static inline size_t dtype_size(int dt) { return dt == AFHIP_BF16 ? 2 : 4; }
 
 // ---- element access in f32 regardless of storage type ----

@@ -679,15 +679,14 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     const size_t lds = big ? 4 * (size_t)TILE2_BYTES : 4 * (size_t)TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
     if (big) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static unsigned long long attr_done = 0;
+        if (afhip_first_use_on_device(&attr_done)) {
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<float, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<float, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<bf16, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
         }
     }
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;

@@ -485,10 +485,9 @@ int pp_num_cus() {
 
 template <int ACT, bool HB, bool HR, bool LF = false, bool ST = false>
 void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    if (afhip_first_use_on_device(&attr_done)) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        attr_done = true;
     }
     hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
 }

@@ -90,14 +90,15 @@ __global__ void add_stream_emb_kernel(const T* __restrict__ hidden, const T* __r
 }
 
 // first-index argmax over the allowed intervals, two passes: AM_G workgroups per row scan interleaved 256-element
-// slices and leave (value, index) partials in a device scratch, one wave per row merges them (ties -> smaller index,
-// like torch.argmax).  Scratch is library-owned and sized for AM_MAXROWS rows; calls on different streams must not overlap.
-constexpr int AM_G = 64, AM_MAXROWS = 256;
-__device__ float g_am_val[AM_MAXROWS * AM_G];
-__device__ int g_am_idx[AM_MAXROWS * AM_G];
+// slices and leave (value, index) partials in the CALLER's scratch (rows x AM_G x 8 bytes), one wave per row merges them
+// (ties -> smaller index, like torch.argmax).  ROUND_BF16: every logit is rounded to bf16 before it is compared -- the
+// reference takes argmax over model-dtype logits (lm/parallel.py:592-601: lm_head output in bf16), so equal bf16 values tie
+// and the first index wins.
+constexpr int AM_G = 64;
 
+template <bool ROUND_BF16>
 __global__ __launch_bounds__(256) void masked_argmax_part_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ iv,
-                                                                 int n_iv) {
+                                                                 int n_iv, float* __restrict__ pval, int* __restrict__ pidx) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void masked_argmax_part_kernel(const float* __
     for (int k = 0; k < n_iv; ++k) {
         const int lo = iv[2 * k], hi = iv[2 * k + 1];
         for (int i = lo + g * 256 + tid; i < hi; i += AM_G * 256) {
-            const float v = row[i];
+            float v = row[i];
+            if (ROUND_BF16) v = (float)(bf16)v;
             if (v > best || (v == best && i < bi)) { best = v; bi = i; }
         }
     }
@@ -122,15 +124,16 @@ __global__ __launch_bounds__(256) void masked_argmax_part_kernel(const float* __
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        g_am_val[r * AM_G + g] = best;
-        g_am_idx[r * AM_G + g] = bi;
+        pval[r * AM_G + g] = best;
+        pidx[r * AM_G + g] = bi;
     }
 }
 
-__global__ __launch_bounds__(64) void masked_argmax_final_kernel(const int32_t* __restrict__ iv, int n_iv, int64_t* __restrict__ token) {
+__global__ __launch_bounds__(64) void masked_argmax_final_kernel(const int32_t* __restrict__ iv, int n_iv, const float* __restrict__ pval,
+                                                                 const int* __restrict__ pidx, int64_t* __restrict__ token) {
     const int r = blockIdx.x, lane = threadIdx.x;
-    float best = g_am_val[r * AM_G + lane];
-    int bi = g_am_idx[r * AM_G + lane];
+    float best = pval[r * AM_G + lane];
+    int bi = pidx[r * AM_G + lane];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -168,6 +171,7 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
     tot += align256((size_t)B * w->vocab * sizeof(float));
     tot += align256((size_t)B * w->n_stream * sizeof(int64_t)) + align256((size_t)B * sizeof(int64_t));
     tot += align256((size_t)B * w->hidden * dtype_size(w->dtype)) * 2;
+    tot += afhip_masked_argmax_workspace_bytes(B);
     return tot;
 }
 
@@ -202,7 +206,7 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         char* kc = (char*)cache->k + (size_t)l * layer_kv;
         char* vc = (char*)cache->v + (size_t)l * layer_kv;
         const bool skinny = rows <= 64;       // decode: RMSNorm and SwiGLU are folded into the weight-streaming GEMMs
-        const bool f8 = skinny && rows <= 32 && dt == AFHIP_BF16 && w->qkv_w8 != nullptr;   // W8A16 copies of the streamed weights
+        const bool f8 = skinny && T == 1 && rows <= 32 && dt == AFHIP_BF16 && w->qkv_w8 != nullptr;   // W8A16 copies of the streamed weights: decode steps only, prefill keeps bf16
         if (skinny) {
             if ((rc = gemm_any(ws.x, f8 ? w->qkv_w8[l] : w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln1_w[l], w->rms_eps, 0, f8 ? w->qkv_s[l] : nullptr))) return rc;
         } else {
@@ -289,12 +293,23 @@ extern "C" int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int
                     nullptr, 0.f, 0, f8 ? w->lm_head_s : nullptr);
 }
 
+extern "C" size_t afhip_masked_argmax_workspace_bytes(int rows) { return rows > 0 ? align256((size_t)rows * AM_G * 8) : 0; }
+
 extern "C" int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
-                                   void* stream) {
-    AFHIP_CHECK(logits && allowed && token && rows > 0 && n_iv > 0 && ld > 0, "afhip_masked_argmax: bad args");
-    AFHIP_CHECK(rows <= AM_MAXROWS, "afhip_masked_argmax: rows=%d exceeds %d", rows, AM_MAXROWS);
-    hipLaunchKernelGGL(masked_argmax_part_kernel, dim3(AM_G, rows), dim3(256), 0, (hipStream_t)stream, logits, ld, allowed, n_iv);
-    hipLaunchKernelGGL(masked_argmax_final_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, allowed, n_iv, token);
+                                   int logits_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(logits && allowed && token && workspace && rows > 0 && n_iv > 0 && ld > 0, "afhip_masked_argmax: bad args");
+    AFHIP_CHECK(logits_dtype == AFHIP_F32 || logits_dtype == AFHIP_BF16, "afhip_masked_argmax: bad logits_dtype");
+    if (workspace_bytes < afhip_masked_argmax_workspace_bytes(rows)) {
+        afhip_set_error("afhip_masked_argmax: workspace %zu < required %zu bytes", workspace_bytes, afhip_masked_argmax_workspace_bytes(rows));
+        return AFHIP_ERR_WORKSPACE;
+    }
+    float* pval = (float*)workspace;
+    int* pidx = (int*)((char*)workspace + (size_t)rows * AM_G * 4);
+    if (logits_dtype == AFHIP_BF16)
+        hipLaunchKernelGGL(masked_argmax_part_kernel<true>, dim3(AM_G, rows), dim3(256), 0, (hipStream_t)stream, logits, ld, allowed, n_iv, pval, pidx);
+    else
+        hipLaunchKernelGGL(masked_argmax_part_kernel<false>, dim3(AM_G, rows), dim3(256), 0, (hipStream_t)stream, logits, ld, allowed, n_iv, pval, pidx);
+    hipLaunchKernelGGL(masked_argmax_final_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, allowed, n_iv, (const float*)pval, (const int*)pidx, token);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -321,13 +336,14 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     int64_t* tok = (int64_t*)(base + off); off += align256((size_t)B * sizeof(int64_t));
     char* emb = base + off; off += align256((size_t)B * H * sz);
     char* hid = base + off; off += align256((size_t)B * H * sz);
+    char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);
     int rc;
     hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);
     AFHIP_LAUNCH_CHECK();
     if ((rc = afhip_embed_sum(ids, w->embed, emb, B, S, H, w->vocab, dt, s))) return rc;
     if ((rc = afhip_llm_forward(w, emb, B, 1, pos, cache, hid, workspace, fwd_bytes, s))) return rc;
     if ((rc = afhip_lm_head(w, hid, B, 1, logits, hs, align256((size_t)B * S * H * sz), s))) return rc;
-    if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, s))) return rc;
+    if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, dt, am, afhip_masked_argmax_workspace_bytes(B), s))) return rc;
     hipLaunchKernelGGL(decode_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, (const int64_t*)tok, st->prev_token, st->out_tokens,
                        st->finished_at, B, step, st->eos_id, st->eot_id);
     AFHIP_LAUNCH_CHECK();

@@ -204,9 +204,9 @@ class ParallelLLM(nn.Module):
         self._ws = None
         return super()._apply(fn, *a, **kw)
 
-    def load_state_dict(self, *a, **kw):
-        self._packed = None
-        return super().load_state_dict(*a, **kw)
+    def _load_from_state_dict(self, *a, **kw):
+        self._packed = None            # fires on every (recursive) load; nested encoders invalidate themselves the same way
+        return super()._load_from_state_dict(*a, **kw)
 
     @property
     def dtype(self):
@@ -339,13 +339,21 @@ class ParallelLLM(nn.Module):
         for io_name, io in self.multimodal_io_dict.items():
             if io.is_discrete:
                 continue
-            if f"{io_name}_indices" not in kwargs or f"{io_name}_feats" not in kwargs or f"{io_name}_lengths" not in kwargs:
+            if f"{io_name}_indices" not in kwargs:
                 continue
-            feats = io.encode_batch(kwargs[f"{io_name}_feats"], kwargs[f"{io_name}_lengths"])
+            if f"{io_name}_encoded" in kwargs:
+                # long-audio path (long_audio.py): the encoder already ran, sharded over the GPUs of the node, and its tokens came
+                # back by the all-gather -- [n, T_w, d] tensor or a list of [len_i, d]; entry i still lands at (b, start, len)
+                feats = kwargs[f"{io_name}_encoded"]
+            elif f"{io_name}_feats" in kwargs and f"{io_name}_lengths" in kwargs:
+                feats = io.encode_batch(kwargs[f"{io_name}_feats"], kwargs[f"{io_name}_lengths"])
+            else:
+                continue
             ad = self.adaptor[io_name]
             for feat, (bidx, start, length) in zip(feats, kwargs[f"{io_name}_indices"].tolist()):
                 n = min(length, feat.shape[0])
-                ops.gemm(feat[:n], ad.weight, bias=ad.bias, out=input_embeds[bidx, start:start + n])
+                if n > 0:
+                    ops.gemm(feat[:n], ad.weight, bias=ad.bias, out=input_embeds[bidx, start:start + n])
         return input_embeds
 
     @torch.no_grad()
@@ -384,6 +392,29 @@ class ParallelLLM(nn.Module):
         if mask is not None:
             logits.masked_fill_(mask, float("-inf"))
         return logits, cache
+
+    @torch.no_grad()
+    def _head_stream0(self, hidden: torch.Tensor) -> torch.Tensor:
+        """Stream-0 logits [n, V] (f32) of final-normed hidden rows [n, H]: the only lm_head rows text decoding consumes
+        (the reference computes all T x 8 rows and slices, lm/parallel.py:588-592,447)."""
+        lib = L.lib()
+        hidden = hidden.contiguous()
+        n = hidden.shape[0]
+        logits = torch.empty((n, self.lm_head.weight.shape[0]), dtype=torch.float32, device=hidden.device)
+        ws = torch.empty(n * hidden.shape[-1] * hidden.element_size() + 256, dtype=torch.uint8, device=hidden.device)
+        L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hidden), n, 1, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return logits
+
+    @torch.no_grad()
+    def _masked_pick(self, logits: torch.Tensor, iv: torch.Tensor) -> torch.Tensor:
+        """First-index argmax over the allowed id intervals, on logits as the MODEL dtype sees them (lm/parallel.py:592-601)."""
+        lib = L.lib()
+        n = logits.shape[0]
+        tok = torch.empty(n, dtype=torch.int64, device=logits.device)
+        am = torch.empty(lib.afhip_masked_argmax_workspace_bytes(n), dtype=torch.uint8, device=logits.device)
+        L.check(lib.afhip_masked_argmax(L.ptr(logits), n, logits.shape[1], L.ptr(iv), iv.shape[0], L.ptr(tok),
+                                        L.dtype_code(self.dtype), L.ptr(am), am.numel(), L.stream_ptr()))
+        return tok
 
     def _logits_to_token(self, logits, temperature, topk):
         """lm/parallel.py:599-608."""
@@ -442,14 +473,8 @@ class ParallelLLM(nn.Module):
         if enforce_modality is not None:
             modality_token = getattr(self, f"{enforce_modality}_token").expand(B0, -1, -1).clone()
         else:
-            lib = L.lib()
             iv, _ = self._allowed_intervals("modality")
-            last = hid[:, -1].contiguous()
-            logits = torch.empty((B0, self.lm_head.weight.shape[0]), dtype=torch.float32, device=device)
-            ws = torch.empty(B0 * hid.shape[-1] * hid.element_size() + 256, dtype=torch.uint8, device=device)
-            L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(last), B0, 1, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
-            tok = torch.empty(B0, dtype=torch.int64, device=device)
-            L.check(lib.afhip_masked_argmax(L.ptr(logits), B0, logits.shape[1], L.ptr(iv), iv.shape[0], L.ptr(tok), L.stream_ptr()))
+            tok = self._masked_pick(self._head_stream0(hid[:, -1]), iv)
             modality_token = torch.zeros((B0, 1, self.num_stream), dtype=torch.int64, device=device)
             modality_token[:, 0, 0] = tok
 

@@ -137,9 +137,12 @@ class AFWhisperEncoder(nn.Module):
         self._ws = None
         return super()._apply(fn, *a, **kw)
 
-    def load_state_dict(self, *a, **kw):
+    def _load_from_state_dict(self, *a, **kw):
+        # nn.Module.load_state_dict recurses through _load_from_state_dict (never through a child's load_state_dict), so this
+        # is the hook that also fires when a PARENT (ParallelLLM, inference.load_checkpoint) loads a checkpoint: the derived
+        # copies (fused q|k|v, tap-major conv, LayerNorm-folded weights) must be rebuilt from the new parameters
         self._packed = None
-        return super().load_state_dict(*a, **kw)
+        return super()._load_from_state_dict(*a, **kw)
 
     @property
     def dtype(self):

@@ -251,7 +251,7 @@ typedef struct {
     const float* rope_cos; const float* rope_sin; /* [max_pos, hd/2] f32 (modeling_qwen2.py:91-103) */
     int rope_max_pos;
     /* optional W8A16 copies of the weights the decode step streams (NULL = off): OCP e4m3 bytes in the same row order
-     * as the bf16 tensors + one f32 scale per output row; used when rows <= 32 and dtype is BF16 */
+     * as the bf16 tensors + one f32 scale per output row; used by decode steps only (T == 1, B <= 32, dtype BF16) */
     const void* const* qkv_w8; const float* const* qkv_s;
     const void* const* o_w8; const float* const* o_s;
     const void* const* gu_w8; const float* const* gu_s;
@@ -276,9 +276,14 @@ int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int rows, int 
                   size_t workspace_bytes, void* stream);
 
 /* Masked greedy pick on stream 0 (lm/parallel.py:594-601): argmax over ids inside `allowed` half-open intervals
- * [lo,hi) (n_iv of them, int32 pairs) with first-index tie-break; writes int64 token[r]. */
+ * [lo,hi) (n_iv of them, int32 pairs) with first-index tie-break; writes int64 token[r].
+ * logits_dtype = the MODEL dtype: the reference takes argmax over lm_head's output in the model dtype, so with AFHIP_BF16 each
+ * f32 logit is rounded to bf16 before it is compared (equal bf16 values tie, first index wins); AFHIP_F32 compares as is.
+ * workspace >= afhip_masked_argmax_workspace_bytes(rows): partial (value, index) pairs; the library keeps no state of its own,
+ * so calls on different streams may overlap. */
+size_t afhip_masked_argmax_workspace_bytes(int rows);
 int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
-                        void* stream);
+                        int logits_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One greedy decode step for B sequences entirely on device: embed prev token (stream 0 = token, others pad),
  * forward 1 position, lm_head on stream 0, masked argmax, append to out_tokens[step], update finished flags

@@ -48,8 +48,12 @@ Cache = List[Tuple[torch.Tensor, torch.Tensor]]
 
 @torch.no_grad()
 def forward(embeds: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: dict,
-            cache: Optional[Cache] = None) -> Tuple[torch.Tensor, Cache]:
-    """embeds [B,T,H] -> (final-normed hidden [B,T,H], new cache). cache[l] = (k,v) each [B,kvh,ctx,hd]."""
+            cache: Optional[Cache] = None, last_layer_rows: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Cache]:
+    """embeds [B,T,H] -> (final-normed hidden [B,T,H], new cache). cache[l] = (k,v) each [B,kvh,ctx,hd].
+
+    last_layer_rows (LongTensor of positions, optional): in the LAST layer only these query positions are computed (keys and
+    values still cover every position) and the result is [B, len(rows), H] -- the same arithmetic, restricted to a row sample,
+    which keeps a 15 000-token check affordable on the CPU."""
     B, T, H = embeds.shape
     nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     hd = H // nh
@@ -66,10 +70,16 @@ def forward(embeds: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: dict,
     for l in range(cfg["num_hidden_layers"]):
         p = f"model.layers.{l}."
         h = rmsnorm(x, sd[p + "input_layernorm.weight"], cfg["rms_norm_eps"])
-        q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(B, T, nh, hd).transpose(1, 2)
+        sub = last_layer_rows if (last_layer_rows is not None and l == cfg["num_hidden_layers"] - 1) else None
+        Tq = T if sub is None else sub.numel()
+        hq = h if sub is None else h[:, sub]
+        q = F.linear(hq, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(B, Tq, nh, hd).transpose(1, 2)
         k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(B, T, nkv, hd).transpose(1, 2)
         v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(B, T, nkv, hd).transpose(1, 2)
-        q = q * cos + _rot_half(q) * sin
+        if sub is None:
+            q = q * cos + _rot_half(q) * sin
+        else:
+            q = q * cos[:, :, sub] + _rot_half(q) * sin[:, :, sub]
         k = k * cos + _rot_half(k) * sin
         if cache:
             k = torch.cat([cache[l][0], k], dim=2)
@@ -78,10 +88,10 @@ def forward(embeds: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: dict,
         rep = nh // nkv
         kk = k[:, :, None].expand(B, nkv, rep, past + T, hd).reshape(B, nh, past + T, hd)
         vv = v[:, :, None].expand(B, nkv, rep, past + T, hd).reshape(B, nh, past + T, hd)
-        s = torch.matmul(q, kk.transpose(2, 3)) * (hd ** -0.5) + amask
+        s = torch.matmul(q, kk.transpose(2, 3)) * (hd ** -0.5) + (amask if sub is None else amask[sub])
         pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
-        o = torch.matmul(pr, vv).transpose(1, 2).reshape(B, T, H)
-        x = x + F.linear(o, sd[p + "self_attn.o_proj.weight"])
+        o = torch.matmul(pr, vv).transpose(1, 2).reshape(B, Tq, H)
+        x = (x if sub is None else x[:, sub]) + F.linear(o, sd[p + "self_attn.o_proj.weight"])
         h = rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg["rms_norm_eps"])
         g = F.linear(h, sd[p + "mlp.gate_proj.weight"])
         u = F.linear(h, sd[p + "mlp.up_proj.weight"])

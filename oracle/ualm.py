@@ -195,7 +195,7 @@ def step(sd, cfg, input_ids=None, input_embeds=None, cache=None, mask=None):
 @torch.no_grad()
 def inference_segment(batch: dict, sd, cfg, enc_sd, enc_cfg, intervals, max_step: int,
                       enforce_modality: Optional[str] = "text", num_stream: int = 8, sdpa=True,
-                      stop_on_eos: bool = True, return_margins: bool = False):
+                      stop_on_eos: bool = True, return_margins: bool = False, input_embeds: Optional[torch.Tensor] = None):
     """inference_segment greedy (lm/parallel.py:428-533), B==1, num_hypo 1, cfg 1.
 
     Returns (tokens [n,S] int64, modality str[, margins list]) -- tokens truncated at the first eos/eot
@@ -207,7 +207,8 @@ def inference_segment(batch: dict, sd, cfg, enc_sd, enc_cfg, intervals, max_step
     a = torch.zeros(1, 1, num_stream, dtype=torch.long)
     a[0, 0, 0] = special_id("<|assistant|>")
     ids = torch.cat([ids, a], dim=1)
-    emb = embed(ids, batch, sd, enc_sd, enc_cfg, sdpa)
+    # input_embeds: the caller already spliced the continuous features (long-audio path: one entry per 30-s window)
+    emb = embed(ids, batch, sd, enc_sd, enc_cfg, sdpa) if input_embeds is None else input_embeds
     logits, cache = step(sd, cfg, input_embeds=emb, mask=mk["modality"])
     logits = logits[:, -1:]
     if enforce_modality is not None:

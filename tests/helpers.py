@@ -138,3 +138,90 @@ def build_tiny_ualm(dtype=torch.float32, device="cuda:0"):
     model.eval()
     pre = ualm_job.UALMPreprocessor(False, {k: v.copy_for_worker() for k, v in ios.items()}, vocab, iv)
     return model, pre
+
+
+# ---------------------------------------------------------------------------------------------------------
+# AF3-7B WIDTHS with few layers (BASELINE config 3 shape): H 3584, 28 q / 4 kv heads x 128, FFN 18944, V 160520
+def stub_continuous(d_model):
+    from audio_intelligence_amd.multimodal_io.abs_io import AbsIO
+
+    class _Cont(AbsIO):
+        """continuous IO whose `feats` already ARE encoder outputs [n, T, d]: exercises adaptor + splice at full width without
+        paying for an encoder"""
+
+        def __init__(self):
+            super().__init__(modality="audio", is_discrete=False)
+
+        def feature_dim(self):
+            return d_model
+
+        def copy_for_worker(self):
+            return self
+
+        def encode_batch(self, feats, lengths):
+            return [f[: int(n)] for f, n in zip(feats, lengths)]
+
+    return _Cont()
+
+
+def wide_llm_cfg(n_layers=2):
+    cfg = dict(oracle.qwen2.config_7b())
+    cfg["num_hidden_layers"] = n_layers
+    return cfg
+
+
+def wide_enc_cfg():
+    cfg = dict(oracle.afwhisper.default_config())
+    cfg["encoder_layers"] = 1
+    return cfg
+
+
+def build_wide_llm(n_layers=2, dtype=torch.bfloat16, device="cuda:0", seed=3, d_enc=1280, real_audio=False, enc_seed=4):
+    """(model on the GPU, f32 CPU state dict holding the SAME values the model computes with, cfg, vocab, intervals).
+    Weights come from the per-tensor seeded generator, are rounded to `dtype` once, and both sides start from the rounded
+    values -- so the only difference left between HIP and oracle is the arithmetic.
+    real_audio: the continuous IO is the real ContinuousAudioIO over a full-width ONE-layer AF-Whisper encoder (the
+    configuration oracle/make_golden_7b.py captured from the reference) instead of the pass-through stub; the returned model
+    then carries the preprocessor as `model._test_pre` and the encoder state dict as `model._test_enc_sd`."""
+    from audio_intelligence_amd.lm.parallel import ParallelLLM
+    from audio_intelligence_amd import ualm_job
+    cfg = wide_llm_cfg(n_layers)
+    text_io, audio_io = stub_ios(cfg["text_vocab"])
+    enc_sd = None
+    if real_audio:
+        from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+        from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+        ecfg = wide_enc_cfg()
+        enc_sd = {k: v.to(dtype) for k, v in syn.synth_state_dict(syn.encoder_param_shapes(ecfg), enc_seed).items()}
+        enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(ecfg))
+        enc.load_state_dict(enc_sd, strict=True)
+        cont = ContinuousAudioIO(encoder_choice="AFWhisper", dtype=str(dtype).replace("torch.", ""), device=device, encoder=enc)
+        enc_sd = {k: v.float() for k, v in enc_sd.items()}
+    else:
+        cont = stub_continuous(d_enc)
+    ios = {"text": text_io, "discrete_audio": audio_io, "continuous_audio": cont}
+    vocab, iv = ualm_job.build_vocabulary(ios)
+    hf = {"architectures": ["Qwen2ForCausalLM"], "hidden_size": cfg["hidden_size"], "num_hidden_layers": n_layers,
+          "num_attention_heads": cfg["num_attention_heads"], "num_key_value_heads": cfg["num_key_value_heads"],
+          "intermediate_size": cfg["intermediate_size"], "rope_theta": cfg["rope_theta"], "rms_norm_eps": cfg["rms_norm_eps"],
+          "vocab_size": cfg["text_vocab"]}
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(device):
+            model = ParallelLLM(hf, ios, vocab, iv)
+    finally:
+        torch.set_default_dtype(old)
+    sd = {}
+    with torch.no_grad():
+        params = dict(model.named_parameters())
+        for name, shape in syn.llm_param_shapes(cfg, len(vocab), 8, d_enc):
+            t = syn.synth_tensor(name, shape, seed).to(dtype)
+            params[name].copy_(t)
+            sd[name] = t.float()
+    model.prepare_inference()
+    model.eval()
+    if real_audio:
+        model._test_pre = ualm_job.UALMPreprocessor(False, {k: v.copy_for_worker() for k, v in ios.items()}, vocab, iv)
+        model._test_enc_sd = enc_sd
+    return model, sd, cfg, vocab, iv

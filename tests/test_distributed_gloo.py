@@ -23,14 +23,59 @@ def _worker(rank, world, port, n_windows, q):
     g = torch.Generator().manual_seed(0)
     wav = torch.randn(n_windows, 64, generator=g)
     n_valid = torch.arange(1, n_windows + 1) * 1000
-    out = encode_windows_sharded(_encode, wav, n_valid)
+    out = encode_windows_sharded(_encode, wav, n_valid, out_spec=(750, 4, torch.float32))
     ref = _encode(wav, n_valid)
     ok = bool(torch.equal(out, ref))
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # bench.py's elapsed-time reduction
-    q.put((rank, ok, float(t.item())))
+    # config 4 end to end with stand-ins for the two GPU pieces (encoder, LLM): window sharding, ONE gather, per-window
+    # (b, start, len) entries and clip ownership must reproduce the single-process result
+    res = _long_audio(rank, world)
+    q.put((rank, ok, float(t.item()), res))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _FakeEnc:
+    class config:
+        max_source_positions = 1500
+
+    def _get_feat_extract_output_lengths(self, n):
+        a = (n - 1) // 2 + 1
+        return a, (a - 2) // 2 + 1
+
+    def encode_btc(self, mel, feat_len=None):
+        w = mel.shape[0]
+        return (mel[:, :4].reshape(w, 1, 4) + feat_len.reshape(w, 1, 1).float()).expand(w, 750, 4).contiguous() + torch.arange(750).reshape(1, 750, 1)
+
+
+class _FakeProc:
+    def extract_device(self, wav, layout="btc", dtype=None):
+        return wav[:, :16].to(dtype)                       # a few samples identify the window
+
+
+class _FakeIO:
+    model, processor, hop_length, d_model, dtype = _FakeEnc(), _FakeProc(), 160, 4, torch.float32
+
+
+class _FakeLLM:
+    device, num_stream, vocab_intervals = torch.device("cpu"), 8, {"text": [(256, 1256)]}
+
+    def inference_segment(self, cfg, cache=None, enforce_modality=None, **b):
+        enc, idx = b["continuous_audio_encoded"], b["continuous_audio_indices"]
+        assert enc.shape[0] == idx.shape[0]
+        digest = [int(b["seqs"].sum()), int(b["seqs"].shape[1])] + [int(x) for x in idx.flatten()] + [int(enc[i, : int(idx[i, 2])].sum()) for i in range(enc.shape[0])]
+        return [(torch.tensor(digest)[:, None], enforce_modality)], None
+
+
+def _long_audio(rank, world):
+    import numpy as np
+    from audio_intelligence_amd.long_audio import long_audio_inference
+    rng = np.random.default_rng(3)
+    clips = [rng.standard_normal(n).astype(np.float32) for n in (75 * 16000, 30 * 16000, 100 * 16000 + 77)]     # 3 + 1 + 4 windows
+    prompts = [[5, 6, 7], [0, 9], [11] * 6]
+    got = long_audio_inference(_FakeLLM(), _FakeIO(), clips, prompts, {"text": {}}, enforce_modality="text")
+    return {c: t[:, 0].tolist() for c, (t, _) in got.items()}
 
 
 def _run(n_windows, port):
@@ -46,6 +91,16 @@ def _run(n_windows, port):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), "gathered tokens differ from the single-process result"
     assert all(r[2] == 2.0 for r in res)
+    # long-audio ownership: clip c belongs to rank c % 2, and every clip's digest equals the single-process one
+    import torch.distributed as d2
+    assert not d2.is_initialized()
+    single = _long_audio(0, 1)
+    merged = {}
+    for r in res:
+        assert set(r[3].keys()) == {c for c in single if c % 2 == r[0]}
+        merged.update(r[3])
+    assert merged == single
+    assert single[0][1] == 3 + 3 + 3 + 750 + 750 + 375 + 1              # bos,user,text + prompt + eot,user,audio + tokens of 30+30+15 s + eos
 
 
 def test_window_shard_all_gather_even():

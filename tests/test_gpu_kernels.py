@@ -277,10 +277,20 @@ def test_masked_argmax_first_index_ties():
     x[2, :] = -float("inf"); x[2, 4500] = -3.0
     iv = torch.tensor([[2, 4], [256, 4800]], dtype=torch.int32)
     tok = torch.zeros(3, dtype=torch.int64, device=_dev())
-    L.check(lib.afhip_masked_argmax(L.ptr(x.to(_dev())), 3, V, L.ptr(iv.to(_dev())), 2, L.ptr(tok), L.stream_ptr()))
+    ws = torch.empty(lib.afhip_masked_argmax_workspace_bytes(3), dtype=torch.uint8, device=_dev())
+    L.check(lib.afhip_masked_argmax(L.ptr(x.to(_dev())), 3, V, L.ptr(iv.to(_dev())), 2, L.ptr(tok), L.F32, L.ptr(ws), ws.numel(), L.stream_ptr()))
     mask = torch.ones(V, dtype=torch.bool); mask[2:4] = False; mask[256:4800] = False
     ref = x.masked_fill(mask[None], float("-inf")).argmax(-1)
     assert tok.cpu().tolist() == ref.tolist() == [700, 2, 4500]
+    # model dtype bf16: the reference's argmax runs over bf16 logits (lm/parallel.py:592-601) -- values that round to the same
+    # bf16 tie and the first index wins, even where the f32 values order them the other way
+    y = _rand(2, V, seed=36)
+    y[0, 300] = 12.00390625; y[0, 2000] = 12.0078125             # both round to bf16 12.0; f32 argmax would be 2000
+    y[1, 4000] = 16.0; y[1, 3000] = 15.984375                     # 15.98.. rounds UP to bf16 16.0 -> ties with 4000, 3000 first
+    L.check(lib.afhip_masked_argmax(L.ptr(y.to(_dev())), 2, V, L.ptr(iv.to(_dev())), 2, L.ptr(tok), L.BF16, L.ptr(ws), ws.numel(), L.stream_ptr()))
+    refb = y.to(torch.bfloat16).masked_fill(mask[None], float("-inf")).argmax(-1)
+    assert tok[:2].cpu().tolist() == refb.tolist() == [300, 3000]
+    assert lib.afhip_masked_argmax(L.ptr(y.to(_dev())), 2, V, L.ptr(iv.to(_dev())), 2, L.ptr(tok), L.BF16, L.ptr(ws), 16, L.stream_ptr()) == -3
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -1,0 +1,115 @@
+"""BASELINE config 4 (long audio) on ONE GPU: the end-to-end path windows -> encoder -> (gather) -> adaptor + per-window splice ->
+causal prefill -> greedy, against the oracle at tiny shape; and the kernels the ~15 000-position prompt of a 10-minute clip
+needs (causal GQA attention at head_dim 128, afhip_llm_forward at 7B widths) against a row-sampled fp32 reference.  The RCCL
+all-gather itself is rehearsed on gloo (tests/test_distributed_gloo.py) and timed by `bench.py --workload long_audio`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import fixtures_common as fc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+
+
+def test_long_audio_end_to_end_tiny_f32_matches_oracle():
+    """75-s and 100-s clips (3 and 4 windows, the last ones short) through long_audio_inference in fp32: greedy ids must equal
+    the oracle's, which encodes the same windows with its SoundTower restatement, splices them entry by entry and decodes."""
+    _need_gpu()
+    from audio_intelligence_amd.long_audio import long_audio_inference, split_windows, build_long_prompt
+    model, pre = H.build_tiny_ualm(torch.float32, DEV)
+    lcfg, lsd, vocab, iv = H.tiny_llm()
+    ecfg, esd = H.tiny_enc()
+    io = model.multimodal_io_dict["continuous_audio"]
+    clips = [fc.make_wav(4242, 75 * 16000), fc.make_wav(4243, 100 * 16000 + 4000)]
+    prompts = [fc.make_prompt(lcfg["text_vocab"]), fc.make_prompt(lcfg["text_vocab"], n=9, seed=8)]
+    cfg = {"text": {"temperature": 0.0, "topk": 20, "cfg": 1, "max_step": 12}, "num_hypo": 1}
+    got = long_audio_inference(model, io, clips, prompts, cfg, enforce_modality="text")
+    assert sorted(got.keys()) == [0, 1]
+    for c, wav in enumerate(clips):
+        spans = split_windows(len(wav))
+        wins = np.zeros((len(spans), 480000), np.float32)
+        for i, (a, b) in enumerate(spans):
+            wins[i, : b - a] = wav[a:b]
+        n_valid = torch.tensor([b - a for a, b in spans])
+        mel = torch.from_numpy(oracle.logmel.log_mel(wins))
+        mask = (torch.arange(3000)[None, :] < (n_valid // 160)[:, None]).long()[:, None, :]
+        tokens = oracle.afwhisper.sound_tower(mel, mask, esd, ecfg)                       # [W,750,d], untrimmed (sound_encoder.py:106-107)
+        seq, entries = build_long_prompt(prompts[c], len(wav), iv["text"][0][0])
+        assert len(entries) == len(spans) and entries[0][1] == 750
+        a_tok = torch.zeros(1, 8, dtype=torch.long)
+        a_tok[0, 0] = oracle.ualm.special_id("<|assistant|>")
+        ids = torch.cat([seq, a_tok])[None]
+        emb = F.embedding(ids, lsd["model.embed_tokens.weight"]).sum(dim=2)
+        for w, (start, n) in enumerate(entries):                                          # lm/parallel.py:277-282, one entry per window
+            emb[0, start:start + n] = F.linear(tokens[w, :n], lsd["adaptor.continuous_audio.weight"], lsd["adaptor.continuous_audio.bias"])
+        ref, modality = oracle.ualm.inference_segment({"seqs": seq[None]}, lsd, lcfg, esd, ecfg, iv, max_step=12, input_embeds=emb)
+        toks, mod = got[c]
+        assert mod == modality == "text"
+        assert toks[:, 0].cpu().tolist() == ref[:, 0].tolist(), f"clip {c}"
+
+
+def _sample_rows(T, n_rand=192, tail=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randperm(T - tail, generator=g)[:n_rand]
+    return torch.cat([torch.tensor([0, 1, 63, 64, 65, 127, 128]), r, torch.arange(T - tail, T)]).unique()
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_causal_gqa_attention_15k_positions(dt):
+    """hd = 128, 4 query heads per kv head, T = 15 104 (20 windows x 750 + prompt, not a multiple of the key tile): sampled query
+    rows against softmax(q k^T / sqrt(d) + causal) v in fp32 on the same (rounded) operands."""
+    _need_gpu()
+    from audio_intelligence_amd import ops
+    T, nq, nkv, hd = 15104 - 37, 4, 1, 128
+    g = torch.Generator().manual_seed(21)
+    q = (torch.randn(1, T, nq * hd, generator=g) * 1.5).to(dt)
+    k = (torch.randn(1, nkv, T + 27, hd, generator=g) * 1.5).to(dt)          # cache layout [B,n_kv,cap,hd], cap > T
+    v = torch.randn(1, nkv, T + 27, hd, generator=g).to(dt)
+    out = ops.attention_cache(q.to(DEV), k.to(DEV), v.to(DEV), nq, nkv, T, 0).float().cpu()
+    rows = _sample_rows(T)
+    qf = q.float()[0, rows].view(-1, nq, hd).transpose(0, 1)                # [nq, r, hd]
+    kf, vf = k.float()[0, 0, :T], v.float()[0, 0, :T]
+    s = torch.matmul(qf, kf.T) / np.sqrt(hd)
+    s = s.masked_fill(torch.arange(T)[None, None, :] > rows[None, :, None], float("-inf"))
+    ref = torch.matmul(torch.softmax(s, -1), vf).transpose(0, 1).reshape(len(rows), nq * hd)
+    err = (out[0, rows] - ref).abs()
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-5
+    assert float(err.max()) <= tol, float(err.max())
+
+
+def test_llm_forward_15k_prompt_7b_widths_bf16():
+    """afhip_llm_forward at the 10-minute prompt length (T = 15 040) and AF3-7B widths, one layer, bf16: sampled positions against
+    oracle/qwen2.py (fp32 arithmetic, same rounded weights, last-layer rows restricted to the sample); plus causality as a
+    size-independent property -- the first 2 048 positions do not depend on the 13 000 that follow."""
+    _need_gpu()
+    model, sd, cfg, vocab, iv = H.build_wide_llm(n_layers=1, dtype=torch.bfloat16, device=DEV)
+    T = 15040
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(1, T, cfg["hidden_size"], generator=g).to(torch.bfloat16)
+    hid, cache = model._forward_hidden(x.to(DEV), model.new_cache(1, T + 64))
+    assert cache.get_seq_length() == T
+    rows = _sample_rows(T, n_rand=96, tail=32, seed=1)
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    ref, _ = oracle.qwen2.forward(x.float(), sd, cfg, last_layer_rows=rows)
+    err = (hid[0, rows].float().cpu() - ref[0]).abs()
+    print(f"T={T} 7B widths 1 layer: sampled hidden err max {float(err.max()):.4f} mean {float(err.mean()):.5f}")
+    assert float(err.mean()) <= 1.2e-2 and float(err.max()) <= 0.2
+    head, _ = model._forward_hidden(x[:, :2048].to(DEV), model.new_cache(1, 2048 + 64))
+    d = (head.float() - hid[:, :2048].float()).abs()
+    assert float(d.max()) <= 3e-2, float(d.max())          # same arithmetic up to tile-order effects of bf16 storage
+    # chunked prefill (the multi-segment / continuation form): positions 8 192.. fed as a second call against the cache
+    hid_a, cache2 = model._forward_hidden(x[:, :8192].to(DEV), model.new_cache(1, T + 64))
+    hid_b, cache2 = model._forward_hidden(x[:, 8192:].to(DEV), cache2)
+    d2 = (torch.cat([hid_a, hid_b], 1).float() - hid.float()).abs()
+    assert float(d2.max()) <= 3e-2, float(d2.max())
