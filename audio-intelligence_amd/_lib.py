@@ -39,7 +39,7 @@ class AttnArgs(C.Structure):
                 ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
                 ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
                 ("q_prescaled", C.c_int), ("new_k", C.c_void_p), ("new_v", C.c_void_p), ("new_kv_batch_stride", C.c_longlong),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p)]
 
 
 class EncoderWeights(C.Structure):
@@ -74,7 +74,14 @@ class KvCache(C.Structure):
 
 class DecodeState(C.Structure):
     _fields_ = [("prev_token", C.c_void_p), ("out_tokens", C.c_void_p), ("finished_at", C.c_void_p),
-                ("allowed", C.c_void_p), ("n_iv", C.c_int), ("eos_id", C.c_int), ("eot_id", C.c_int)]
+                ("allowed", C.c_void_p), ("n_iv", C.c_int), ("eos_id", C.c_int), ("eot_id", C.c_int),
+                ("seq_pos", C.c_void_p), ("step_counter", C.c_void_p)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("cfg_logits", C.c_void_p), ("cfg", C.c_float), ("rows", C.c_int), ("ld", C.c_int),
+                ("allowed", C.c_void_p), ("n_iv", C.c_int), ("k", C.c_int), ("temperature", C.c_float), ("model_dtype", C.c_int),
+                ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p), ("topk_prob", C.c_void_p), ("u", C.c_void_p), ("token", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/afhip.h one to one (tests/test_cabi.py checks the header against this)
@@ -104,9 +111,11 @@ SIGNATURES = {
     "afhip_encoder_forward": (_I, [C.POINTER(EncoderWeights), _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I, _I]),
     "afhip_llm_forward": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
+    "afhip_llm_forward_ragged": (_I, [C.POINTER(LlmWeights), _P, _I, _P, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
     "afhip_lm_head": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _P, _P, _Z, _P]),
     "afhip_masked_argmax_workspace_bytes": (_Z, [_I]),
     "afhip_masked_argmax": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _Z, _P]),
+    "afhip_sample_topk": (_I, [C.POINTER(SampleArgs), _P]),
     "afhip_llm_decode_step": (_I, [C.POINTER(LlmWeights), C.POINTER(KvCache), C.POINTER(DecodeState), _I, _I, _I, _P, _Z, _P]),
 }
 

@@ -14,3 +14,14 @@ void afhip_set_error(const char* fmt, ...) {
 
 extern "C" int afhip_version(void) { return 100; }
 extern "C" const char* afhip_last_error(void) { return g_err; }
+
+int afhip_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}

@@ -37,6 +37,8 @@ struct AttnP {
     const float* rope_cos;
     const float* rope_sin;
     int* ticket;            // split mode: in-launch merge by the last-arriving key-range workgroup (afhip.h); NULL = separate pass
+    const int32_t* seq_pos; // split mode: per-sequence position of the token being generated, read on the DEVICE (Tk_b = seq_pos[b] + 1,
+                            // RoPE row, append slot); p.Tk is then only the host's upper bound that sized the grid.  NULL = uniform p.Tk
     unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
 };
 
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const char* vb = p.v + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
 
     int klen = p.Tk;
+    if (p.seq_pos) { const int tk = p.seq_pos[b] + 1; klen = tk < klen ? tk : klen; }   // wave-uniform (b is per workgroup)
+    const int tk_b = klen;                                  // keys of THIS sequence (== p.Tk without seq_pos)
     if (p.key_len) { const int kl = p.key_len[b]; klen = kl < klen ? kl : klen; }
     int kend = klen;                                       // keys this workgroup must visit
     if (p.causal) {
@@ -114,8 +118,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         kbeg = split * p.key_split;
         const int ke = kbeg + p.key_split;
         kend = ke < kend ? ke : kend;
+        if (p.seq_pos && kbeg >= kend) return;             // key range beyond this sequence's context: nothing to do, the combine
+                                                           // pass derives the number of live ranges from seq_pos as well
         if (kbeg > kend) kbeg = kend;
     }
+    const float* rope_cos = p.rope_cos;
+    const float* rope_sin = p.rope_sin;
+    if (p.seq_pos && p.new_k) { rope_cos += (long long)(tk_b - 1) * (HD / 2); rope_sin += (long long)(tk_b - 1) * (HD / 2); }
     const int tbeg = kbeg / KT;
     const int ntiles = (kend + KT - 1) / KT;      // tiles [tbeg, ntiles)
 
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = dc * 16 + fh * 8 + e;
-                    const float c = p.rope_cos[i], sn = p.rope_sin[i];
+                    const float c = rope_cos[i], sn = rope_sin[i];
                     const float x1 = to_f32<T>(qf[dc][e]), x2 = to_f32<T>(qf[dc + DSTEPS / 2][e]);
                     qf[dc][e] = from_f32<T>(rope_mad(x1, c, -x2, sn));
                     qf[dc + DSTEPS / 2][e] = from_f32<T>(rope_mad(x2, c, x1, sn));
@@ -156,11 +165,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             const int c = tid + 256 * i;
             const int row = c / KCPR, cc = c % KCPR;
             int key = k0 + row;
-            key = key < p.Tk ? key : p.Tk - 1;
+            key = key < tk_b ? key : tk_b - 1;
             const long long off = ((long long)key * p.ld_kv) * SZ + cc * 16;
             rk[i] = ld16(kb + off);
             rv[i] = ld16(vb + off);
-            if (p.new_k && k0 + row == p.Tk - 1) {
+            if (p.new_k && k0 + row == tk_b - 1) {
                 // fused KV append (decode): this chunk of the token being generated comes from the projection output, not from
                 // the cache; k is rotated here (partner elements d +- HD/2 sit KCPR/2 chunks away in the same row), and both are
                 // written to the cache for the following steps.  Only the workgroup whose key range holds Tk-1 gets here.
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 T ov[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float c = p.rope_cos[i0 + e], sn = p.rope_sin[i0 + e];
+                    const float c = rope_cos[i0 + e], sn = rope_sin[i0 + e];
                     const float xo = to_f32<T>(reinterpret_cast<const T*>(&own)[e]), xp = to_f32<T>(reinterpret_cast<const T*>(&par)[e]);
                     // first half: x1 = own, x2 = partner -> x1 c - x2 s;  second half: x2 = own, x1 = partner -> x2 c + x1 s
                     ov[e] = from_f32<T>(lo ? rope_mad(xo, c, -xp, sn) : rope_mad(xo, c, xp, sn));
@@ -354,6 +363,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             if (fh == 0) { p.part_ml[slot * 2] = m_i; p.part_ml[slot * 2 + 1] = l_tot; }
         }
         if (p.ticket == nullptr) return;
+        const int n_live = p.seq_pos ? (tk_b + p.key_split - 1) / p.key_split : p.n_xt;
         // ---- in-launch merge (cdna guide, Guideline 16 counter form): publish, take a ticket, the last arriver merges ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's partial stores have left
         __syncthreads();                                                   // ... and every wave's
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // keep: ROCm 7.2 can drop the fence's own wait
             const int tk = __hip_atomic_fetch_add(p.ticket + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag[0] = (tk == p.n_xt - 1) ? 1 : 0;
+            flag[0] = (tk == n_live - 1) ? 1 : 0;
         }
         __syncthreads();
         if (flag[0] == 0) return;                                          // wave-uniform
@@ -375,9 +385,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         for (int idx = tid; idx < p.Tq * HD; idx += 256) {
             const int qr = idx / HD, d = idx - qr * HD;
             float m = -INFINITY;
-            for (int sp = 0; sp < p.n_xt; ++sp) m = fmaxf(m, p.part_ml[((((long long)sp * p.B + b) * p.n_q + hq) * 32 + qr) * 2]);
+            for (int sp = 0; sp < n_live; ++sp) m = fmaxf(m, p.part_ml[((((long long)sp * p.B + b) * p.n_q + hq) * 32 + qr) * 2]);
             float l = 0.f, o = 0.f;
-            for (int sp = 0; sp < p.n_xt; ++sp) {
+            for (int sp = 0; sp < n_live; ++sp) {
                 const long long slot = (((long long)sp * p.B + b) * p.n_q + hq) * 32 + qr;
                 const float ms = p.part_ml[slot * 2];
                 const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
@@ -419,6 +429,7 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
     const int row = blockIdx.x;                      // (b, hq, qrow) flattened
     const int qrow = row % p.Tq, hq = (row / p.Tq) % p.n_q, b = row / (p.Tq * p.n_q);
     const int d = threadIdx.x;
+    if (p.seq_pos) { const int live = (p.seq_pos[b] + 1 + p.key_split - 1) / p.key_split; n_split = live < n_split ? live : n_split; }
     float m = -INFINITY;
     for (int s = 0; s < n_split; ++s) {
         const long long slot = (((long long)s * p.B + b) * p.n_q + hq) * 32 + qrow;
@@ -481,6 +492,8 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.new_k = (const char*)a->new_k; p.new_v = (const char*)a->new_v; p.new_kv_bs = a->new_kv_batch_stride;
     p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
     p.ticket = a->key_split > 0 ? a->split_ticket : nullptr;
+    p.seq_pos = a->seq_pos;
+    if (a->seq_pos) AFHIP_CHECK(a->key_split > 0, "afhip_attention: seq_pos needs the split-context (decode) form, key_split > 0");
     if (a->new_k) {
         AFHIP_CHECK(a->key_split > 0 && a->new_v && a->rope_cos && a->rope_sin, "afhip_attention: fused RoPE/append needs key_split > 0, new_v and the cos/sin rows");
         AFHIP_CHECK(((uintptr_t)a->new_k % 16) == 0 && ((uintptr_t)a->new_v % 16) == 0 && (a->new_kv_batch_stride * sz) % 16 == 0, "afhip_attention: new_k / new_v must keep 16-byte alignment");

@@ -45,6 +45,9 @@ static inline bool afhip_first_use_on_device(unsigned long long* done_mask) {
 }
 static inline size_t dtype_size(int dt) { return dt == AFHIP_BF16 ? 2 : 4; }
 
+// compute units of the current device (cached per process; 256 on MI355X)
+int afhip_cu_count();
+
 // ---- element access in f32 regardless of storage type ----
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

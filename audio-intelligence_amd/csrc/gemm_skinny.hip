@@ -42,6 +42,7 @@ struct SkinnyP {
     int out_f32;
     float norm_eps;
     int swiglu_out;
+    int tile_rows;   // weight rows per 16-wide MFMA tile that carry work (<= 16): narrow outputs are cut into ceil(N / CUs)-row shares so every CU streams the same bytes
 };
 
 template <typename T> struct Step;
@@ -71,7 +72,9 @@ template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
     return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
 
-template <int NT, int MT> struct StepRegs { u32x4 w0[NT], w1[NT], a0[MT], a1[MT], x0[MT], x1[MT], n0, n1; };
+// x0 / x1 (the up half of an interleaved gate/up A operand) exist only in A_SWIGLU mode: with MT = 4 they were 32 dead registers per
+// step set and pushed skinny_kernel<*, 1, 4, *> into scratch
+template <int NT, int MT, int XM> struct StepRegs { u32x4 w0[NT], w1[NT], a0[MT], a1[MT], x0[XM], x1[XM], n0, n1; };
 
 template <typename T, int NT, int MT, int AMODE, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
@@ -86,12 +89,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
     // (j = b >> 1, t = b & 1) of the 32-row interleaved gate/up weight: 16-row granularity keeps the per-CU byte share even
     const bool pair = (NT == 2) && p.swiglu_out;
-    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * 16);
+    const int TR = pair ? 16 : p.tile_rows;
+    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * TR);
+    const int cr = c16 < TR ? c16 : TR - 1;           // lanes past the share re-read its last row (same line: no extra traffic), their results are dropped
 
     const char* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n_base + (pair ? t * 32 : t * 16) + c16;
+        int n = n_base + (pair ? t * 32 + c16 : t * TR + cr);
         n = n < p.N ? n : p.N - 1;
         wrow[t] = p.W + (long long)n * p.ldw * SZ;
     }
@@ -114,7 +119,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
 
     const int nsteps = p.K / KS;
 
-    auto issue = [&](int s, StepRegs<NT, MT>& r) {
+    constexpr int XM = AMODE == A_SWIGLU ? MT : 1;
+    typedef StepRegs<NT, MT, XM> Regs;
+    auto issue = [&](int s, Regs& r) {
         const long long koff = (long long)s * KS * SZ + q * 32;          // byte offset of this lane's 32 B inside a K row
 #pragma unroll
         for (int t = 0; t < NT; ++t) { r.w0[t] = ld16(wrow[t] + koff); r.w1[t] = ld16(wrow[t] + koff + 16); }
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
             if constexpr (AMODE == A_RMSNORM) { r.n0 = ld16(p.norm_w + koff); r.n1 = ld16(p.norm_w + koff + 16); }
         }
     };
-    auto consume = [&](StepRegs<NT, MT>& r) {
+    auto consume = [&](Regs& r) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if constexpr (AMODE == A_RMSNORM) {
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     // K = 3584 a wave only has 7 steps).  Steps are still consumed in ascending order: sums are bit-identical.
     {
         constexpr int DEPTH = NT == 1 ? SKINNY_DEPTH1 : SKINNY_DEPTH;   // register sets = K steps in flight per wave
-        StepRegs<NT, MT> r[DEPTH];
+        Regs r[DEPTH];
         int sx[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -254,10 +261,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
-        const int n = n_base + nt * 16 + (ln & 15);
+        const int n = n_base + nt * TR + (ln & 15);
         const int mrow = 4 * (ln >> 4) + reg;
         const int m = mt * 16 + mrow;
-        if (n < p.N && m < p.M) {
+        if ((ln & 15) < TR && n < p.N && m < p.M) {
             if constexpr (AMODE == A_RMSNORM) {
                 float sq = 0.f;
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
 template <typename T, int NT, int MT>
 void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
     constexpr int NW = (NT == 1 && sizeof(T) == 2 && MT <= 2) ? SKINNY_NW1 : 8;
-    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(NW * 64);
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(NW * 64);
     const size_t lds = ((size_t)NW * NT * MT * 256 + NW * MT * 16) * sizeof(float);
     switch (amode) {
         case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM, NW>), grid, block, lds, s, p); break;
@@ -332,13 +339,26 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     const bool wide = a->N >= 8192 && mt <= 2;   // NT=4 needs 8*NT*MT KiB of LDS for the K-slice combine
     if (sw_out) AFHIP_CHECK(wide && a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm_skinny: SWIGLU epilogue needs N >= 8192, N %% 64 == 0, M <= 32, no bias/residual");
     p.swiglu_out = sw_out ? 1 : 0;
+    p.tile_rows = 16;
+    // narrow outputs (the 3584 / 4608-wide decoder projections): 16-row tiles give 224 or 288 workgroups on 256 CUs -- 12 % of the
+    // chip idle, or a second round for 32 of them.  Cut N into one share of ceil(N / CUs) rows per CU instead (14 rows x 256 for
+    // N = 3584, 2 x 9 rows x 256 for N = 4608): every CU streams the same bytes.  A row's K order does not change: same bits.
+    int nt_narrow = 1;
+    if (!wide && !sw_out) {
+        const int rpw = cdiv(a->N, afhip_cu_count());
+        nt_narrow = rpw <= 16 ? 1 : 2;
+        p.tile_rows = rpw <= 16 ? rpw : (rpw <= 32 ? cdiv(rpw, 2) : 16);
+        if (mt > 2 && nt_narrow == 2) { nt_narrow = 1; p.tile_rows = 16; }      // LDS of the K-slice combine: NT * MT <= 4 tiles
+    }
     if (a->dtype == AFHIP_BF16) {
         if (sw_out) launch_mt<bf16, 2>(p, mt, amode, s);
         else if (wide) launch_mt<bf16, 4>(p, mt, amode, s);
+        else if (nt_narrow == 2) launch_mt<bf16, 2>(p, mt, amode, s);
         else launch_mt<bf16, 1>(p, mt, amode, s);
     } else {
         if (sw_out) launch_mt<float, 2>(p, mt, amode, s);
         else if (wide) launch_mt<float, 4>(p, mt, amode, s);
+        else if (nt_narrow == 2) launch_mt<float, 2>(p, mt, amode, s);
         else launch_mt<float, 1>(p, mt, amode, s);
     }
     AFHIP_LAUNCH_CHECK();

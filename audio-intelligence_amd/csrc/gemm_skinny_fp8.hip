@@ -32,6 +32,7 @@ struct SkinnyF8P {
     int out_f32;
     float norm_eps;
     int swiglu_out;
+    int tile_rows;   // weight rows per 16-wide MFMA tile that carry work (<= 16): narrow outputs are cut into ceil(N / CUs)-row shares so every CU streams the same bytes
 };
 
 constexpr int KS8 = 128;
@@ -60,12 +61,14 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
     // (j = b >> 1, t = b & 1) of the 32-row interleaved gate/up weight: 16-row granularity keeps the per-CU byte share even
     const bool pair = (NT == 2) && p.swiglu_out;
-    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * 16);
+    const int TR = pair ? 16 : p.tile_rows;
+    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * TR);
+    const int cr = c16 < TR ? c16 : TR - 1;           // lanes past the share re-read its last row (same line: no extra traffic), their results are dropped
 
     const char* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n_base + (pair ? t * 32 : t * 16) + c16;
+        int n = n_base + (pair ? t * 32 + c16 : t * TR + cr);
         n = n < p.N ? n : p.N - 1;
         wrow[t] = p.W + (long long)n * p.ldw;
     }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
 
     // rolling window of two steps per wave (see gemm_skinny.hip): a register set is re-issued as soon as it is consumed
     {
-        constexpr int DEPTH = NT == 1 ? SKINNY_DEPTH1 : SKINNY_DEPTH;   // register sets = K steps in flight per wave
+        constexpr int DEPTH = (NT * MT >= 8) ? 1 : (NT == 1 ? SKINNY_DEPTH1 : SKINNY_DEPTH);   // NT * MT = 8 tiles: one step set in flight (two spill)   // register sets = K steps in flight per wave
         StepRegs8<NT, MT> r[DEPTH];
         int sx[DEPTH];
 #pragma unroll
@@ -219,9 +222,9 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[((((w * NT + nt) * MT + mt) * 64 + ln) << 2) + reg];
-        const int n = n_base + nt * 16 + (ln & 15);
+        const int n = n_base + nt * TR + (ln & 15);
         const int mrow = 4 * (ln >> 4) + reg, m = mt * 16 + mrow;
-        if (n < p.N && m < p.M) {
+        if ((ln & 15) < TR && n < p.N && m < p.M) {
             v *= row_scale(mt, mrow) * p.wscale[n];
             if (p.bias) v += (float)reinterpret_cast<const bf16*>(p.bias)[n];
             if (p.res) v += (float)reinterpret_cast<const bf16*>(p.res)[(long long)m * p.ldres + n];
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
 
 template <int NT, int MT>
 void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
-    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * 16)), block(512);
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(512);
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
     if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_RMSNORM>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_PLAIN>), grid, block, lds, s, p);
@@ -269,8 +272,16 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     p.swiglu_out = sw_out ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int amode = a->a_norm_w ? A_RMSNORM : A_PLAIN;
+    p.tile_rows = 16;
+    int nt_narrow = 1;
+    if (!wide && !sw_out) {                 // one equal share of weight rows per CU (gemm_skinny.hip)
+        const int rpw = cdiv(a->N, afhip_cu_count());
+        nt_narrow = rpw <= 16 ? 1 : 2;
+        p.tile_rows = rpw <= 16 ? rpw : (rpw <= 32 ? cdiv(rpw, 2) : 16);
+    }
     if (sw_out) launch_mt8<2>(p, mt, amode, s);
     else if (wide) launch_mt8<4>(p, mt, amode, s);
+    else if (nt_narrow == 2) launch_mt8<2>(p, mt, amode, s);
     else launch_mt8<1>(p, mt, amode, s);
     AFHIP_LAUNCH_CHECK();
     return 0;

@@ -151,13 +151,18 @@ __global__ void build_ids_kernel(const int64_t* __restrict__ prev, int64_t* __re
 }
 
 __global__ void decode_update_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ prev, int64_t* __restrict__ out_tokens,
-                                     int32_t* __restrict__ finished_at, int B, int step, int eos, int eot) {
+                                     int32_t* __restrict__ finished_at, int B, int step, int eos, int eot,
+                                     int32_t* __restrict__ seq_pos, int32_t* __restrict__ step_counter) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (step_counter) step = step_counter[0];          // every thread reads it before thread 0 of this (single) block bumps it
     const int64_t t = tok[b];
     out_tokens[(long long)step * B + b] = t;
     prev[b] = t;
     if ((t == eos || t == eot) && finished_at[b] < 0) finished_at[b] = step;
+    if (seq_pos) seq_pos[b] += 1;
+    __syncthreads();
+    if (step_counter && b == 0) step_counter[0] = step + 1;
 }
 
 }  // namespace
@@ -175,9 +180,12 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
     return tot;
 }
 
-extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
-                                 void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
+                            void* hidden_out, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seq_pos) {
     AFHIP_CHECK(w && x && cache && hidden_out && workspace, "afhip_llm_forward: null pointer");
+    // seq_pos != NULL (T == 1 only): every sequence's position lives on the device; pos0 is then the largest position any of them
+    // may hold during this call (it sizes the grid of the split-context attention and is range-checked here instead)
+    AFHIP_CHECK(seq_pos == nullptr || (T == 1 && w->n_q / w->n_kv <= 32), "afhip_llm_forward_ragged: one token per sequence, <= 32 query heads per kv head");
     AFHIP_CHECK(B > 0 && T > 0 && pos0 >= 0, "afhip_llm_forward: bad B=%d T=%d pos0=%d", B, T, pos0);
     AFHIP_CHECK(w->dtype == AFHIP_F32 || w->dtype == AFHIP_BF16, "afhip_llm_forward: bad dtype");
     AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_forward: head_dim %d unsupported", w->hd);
@@ -232,7 +240,9 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
             a.causal = 0; a.q_pos0 = 0;
             a.key_split = DECODE_KEY_SPLIT; a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
             a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
-            a.rope_cos = w->rope_cos + (size_t)pos0 * (hd / 2); a.rope_sin = w->rope_sin + (size_t)pos0 * (hd / 2);
+            a.seq_pos = seq_pos;
+            a.rope_cos = seq_pos ? w->rope_cos : w->rope_cos + (size_t)pos0 * (hd / 2);
+            a.rope_sin = seq_pos ? w->rope_sin : w->rope_sin + (size_t)pos0 * (hd / 2);
             // the in-launch merge (a.split_ticket = ws.ticket + l * B * nkv) is correct and bit-identical but SLOWER here: 4.10 vs 3.76 ms
             // per 7B step -- 224 workgroups each paying an agent-scope release (L2 write-back) cost more than one 5-us combine launch
             a.split_ticket = DECODE_IN_LAUNCH_MERGE ? ws.ticket + (size_t)l * B * nkv : nullptr;
@@ -266,6 +276,17 @@ extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int 
         }
     }
     return afhip_rmsnorm(ws.x, w->norm_w, hidden_out, rows, H, w->rms_eps, dt, s);
+}
+
+extern "C" int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
+                                 void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return llm_forward_impl(w, x, B, T, pos0, cache, hidden_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int afhip_llm_forward_ragged(const afhip_llm_weights* w, const void* x, int B, const int32_t* seq_pos, int max_pos,
+                                        afhip_kv_cache* cache, void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(seq_pos != nullptr && max_pos >= 0, "afhip_llm_forward_ragged: seq_pos / max_pos");
+    return llm_forward_impl(w, x, B, 1, max_pos, cache, hidden_out, workspace, workspace_bytes, stream, seq_pos);
 }
 
 extern "C" int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int rows, int n_s, float* logits, void* workspace,
@@ -341,11 +362,13 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);
     AFHIP_LAUNCH_CHECK();
     if ((rc = afhip_embed_sum(ids, w->embed, emb, B, S, H, w->vocab, dt, s))) return rc;
-    if ((rc = afhip_llm_forward(w, emb, B, 1, pos, cache, hid, workspace, fwd_bytes, s))) return rc;
+    AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
+    if ((rc = llm_forward_impl(w, emb, B, 1, pos, cache, hid, workspace, fwd_bytes, s, st->seq_pos))) return rc;
     if ((rc = afhip_lm_head(w, hid, B, 1, logits, hs, align256((size_t)B * S * H * sz), s))) return rc;
     if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, dt, am, afhip_masked_argmax_workspace_bytes(B), s))) return rc;
-    hipLaunchKernelGGL(decode_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, (const int64_t*)tok, st->prev_token, st->out_tokens,
-                       st->finished_at, B, step, st->eos_id, st->eot_id);
+    AFHIP_CHECK(B <= 1024, "afhip_llm_decode_step: B=%d > 1024", B);
+    hipLaunchKernelGGL(decode_update_kernel, dim3(1), dim3((B + 63) / 64 * 64), 0, s, (const int64_t*)tok, st->prev_token, st->out_tokens,
+                       st->finished_at, B, step, st->eos_id, st->eot_id, st->seq_pos, st->step_counter);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -103,6 +103,78 @@ class _Backbone(nn.Module):
         self.norm = _Norm(H, bias=False)
 
 
+def _quantize_rows_e4m3(w: torch.Tensor):
+    """[N,K] -> (e4m3 bytes [N,K] as uint8, f32 scale [N]) with w ~= scale[n] * q[n,k]; 448 = e4m3 max."""
+    amax = w.float().abs().amax(dim=1).clamp_min(1e-12)
+    scale = (amax / 448.0).contiguous()
+    q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale
+
+
+def pack_qwen2_weights(backbone: "_Backbone", lm_head_w: torch.Tensor, stream_emb_w: Optional[torch.Tensor], cfg: dict, n_stream: int,
+                       fp8: bool = False, max_positions: Optional[int] = None):
+    """Build `afhip_llm_weights` for a Qwen2 decoder stack held in HF parameter layout: q|k|v fused with biases, gate/up
+    interleaved in 32-row blocks (SwiGLU pairs land in one wave's accumulators), RoPE tables exactly as transformers computes
+    them (modeling_qwen2.py:91-121), optional e4m3 copies of the weights a decode step streams.  Keeps every tensor alive in
+    the returned namespace.  Shared by ParallelLLM (UALM) and Qwen2AudioForConditionalGeneration (AF3)."""
+    dev, dt = lm_head_w.device, lm_head_w.dtype
+    if dev.type != "cuda":
+        raise L.AfhipError("the LLM runs on the GPU only: call .to('cuda') first (no CPU fallback)")
+    H, nq, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg.get("head_dim") or H // nq
+    I = cfg["intermediate_size"]
+    max_pos = max(max_positions or 0, 4096)
+    keep = []
+
+    def P(t):
+        t = t.detach().contiguous()
+        keep.append(t)
+        return t
+
+    w = L.LlmWeights()
+    w.hidden, w.n_layers, w.n_q, w.n_kv, w.hd, w.inter = H, cfg["num_hidden_layers"], nq, nkv, hd, I
+    w.vocab, w.n_stream, w.rms_eps, w.dtype = lm_head_w.shape[0], n_stream, float(cfg.get("rms_norm_eps", 1e-6)), L.dtype_code(dt)
+    w.embed = P(backbone.embed_tokens.weight).data_ptr()
+    names = ["ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gu_w", "down_w"]
+    lists = {n: [] for n in names}
+    for lyr in backbone.layers:
+        a, m = lyr.self_attn, lyr.mlp
+        lists["ln1_w"].append(P(lyr.input_layernorm.weight))
+        lists["qkv_w"].append(P(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)))
+        lists["qkv_b"].append(P(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0)))
+        lists["o_w"].append(P(a.o_proj.weight))
+        lists["ln2_w"].append(P(lyr.post_attention_layernorm.weight))
+        g, u = m.gate_proj.weight, m.up_proj.weight
+        lists["gu_w"].append(P(torch.stack([g.view(I // 32, 32, H), u.view(I // 32, 32, H)], dim=1).reshape(2 * I, H)))
+        lists["down_w"].append(P(m.down_proj.weight))
+    arrays = {}
+    for n in names:
+        arrays[n] = L.ptr_array(lists[n])
+        setattr(w, n, C.cast(arrays[n], L.c_void_pp))
+    if fp8:
+        for src, dst_w, dst_s in (("qkv_w", "qkv_w8", "qkv_s"), ("o_w", "o_w8", "o_s"), ("gu_w", "gu_w8", "gu_s"), ("down_w", "down_w8", "down_s")):
+            qs, ss = [], []
+            for t in lists[src]:
+                q8, sc = _quantize_rows_e4m3(t)
+                qs.append(P(q8))
+                ss.append(P(sc))
+            arrays[dst_w], arrays[dst_s] = L.ptr_array(qs), L.ptr_array(ss)
+            setattr(w, dst_w, C.cast(arrays[dst_w], L.c_void_pp))
+            setattr(w, dst_s, C.cast(arrays[dst_s], L.c_void_pp))
+        q8, sc = _quantize_rows_e4m3(lm_head_w.detach())
+        w.lm_head8, w.lm_head_s = P(q8).data_ptr(), P(sc).data_ptr()
+    w.norm_w = P(backbone.norm.weight).data_ptr()
+    w.lm_head = P(lm_head_w).data_ptr()
+    w.stream_emb = P(stream_emb_w).data_ptr() if stream_emb_w is not None else None
+    # rotary tables exactly as transformers computes them (modeling_qwen2.py:91-103,110-121): f32 on the host
+    theta = float(cfg.get("rope_theta", 10000.0))
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+    fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
+    cos, sin = P(fr.cos().to(dev)), P(fr.sin().to(dev))
+    w.rope_cos, w.rope_sin, w.rope_max_pos = cos.data_ptr(), sin.data_ptr(), max_pos
+    return SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv)
+
+
 class ParallelLLM(nn.Module):
     """Parallel multimodal LLM supporting multi-stream token processing (inference path)."""
 
@@ -133,6 +205,8 @@ class ParallelLLM(nn.Module):
         self._allowed = {}
         self._fp8_decode = False
 
+    _quantize_rows_e4m3 = staticmethod(_quantize_rows_e4m3)
+
     def enable_fp8_decode(self, on: bool = True):
         """W8A16 decode (BASELINE config 5): keep an OCP-e4m3 copy (+ one f32 scale per output row) of every weight the
         decode step streams -- q/k/v, o, gate/up, down, lm_head -- and let the skinny GEMMs read those (half the HBM bytes
@@ -142,14 +216,6 @@ class ParallelLLM(nn.Module):
         self._fp8_decode = bool(on)
         self._packed = None
         return self
-
-    @staticmethod
-    def _quantize_rows_e4m3(w: torch.Tensor):
-        """[N,K] -> (e4m3 bytes [N,K] as uint8, f32 scale [N]) with w ~= scale[n] * q[n,k]; 448 = e4m3 max."""
-        amax = w.float().abs().amax(dim=1).clamp_min(1e-12)
-        scale = (amax / 448.0).contiguous()
-        q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
-        return q.view(torch.uint8).contiguous(), scale
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -220,63 +286,8 @@ class ParallelLLM(nn.Module):
     def pack(self, max_positions: Optional[int] = None):
         if self._packed is not None and (max_positions is None or max_positions <= self._packed.max_pos):
             return self._packed
-        cfg = self.cfg
-        dev, dt = self.device, self.dtype
-        if dev.type != "cuda":
-            raise L.AfhipError("ParallelLLM runs on the GPU only: call .to('cuda') first (no CPU fallback)")
-        H, nq, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
-        hd = cfg.get("head_dim") or H // nq
-        I = cfg["intermediate_size"]
-        max_pos = max(max_positions or 0, 4096)
-        keep = []
-
-        def P(t):
-            t = t.detach().contiguous()
-            keep.append(t)
-            return t
-
-        w = L.LlmWeights()
-        w.hidden, w.n_layers, w.n_q, w.n_kv, w.hd, w.inter = H, cfg["num_hidden_layers"], nq, nkv, hd, I
-        w.vocab, w.n_stream, w.rms_eps, w.dtype = self.lm_head.weight.shape[0], self.num_stream, float(cfg.get("rms_norm_eps", 1e-6)), L.dtype_code(dt)
-        w.embed = P(self.model.embed_tokens.weight).data_ptr()
-        names = ["ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gu_w", "down_w"]
-        lists = {n: [] for n in names}
-        for lyr in self.model.layers:
-            a, m = lyr.self_attn, lyr.mlp
-            lists["ln1_w"].append(P(lyr.input_layernorm.weight))
-            lists["qkv_w"].append(P(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)))
-            lists["qkv_b"].append(P(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0)))
-            lists["o_w"].append(P(a.o_proj.weight))
-            lists["ln2_w"].append(P(lyr.post_attention_layernorm.weight))
-            g, u = m.gate_proj.weight, m.up_proj.weight
-            lists["gu_w"].append(P(torch.stack([g.view(I // 32, 32, H), u.view(I // 32, 32, H)], dim=1).reshape(2 * I, H)))
-            lists["down_w"].append(P(m.down_proj.weight))
-        arrays = {}
-        for n in names:
-            arrays[n] = L.ptr_array(lists[n])
-            setattr(w, n, C.cast(arrays[n], L.c_void_pp))
-        if self._fp8_decode:
-            for src, dst_w, dst_s in (("qkv_w", "qkv_w8", "qkv_s"), ("o_w", "o_w8", "o_s"), ("gu_w", "gu_w8", "gu_s"), ("down_w", "down_w8", "down_s")):
-                qs, ss = [], []
-                for t in lists[src]:
-                    q8, sc = self._quantize_rows_e4m3(t)
-                    qs.append(P(q8))
-                    ss.append(P(sc))
-                arrays[dst_w], arrays[dst_s] = L.ptr_array(qs), L.ptr_array(ss)
-                setattr(w, dst_w, C.cast(arrays[dst_w], L.c_void_pp))
-                setattr(w, dst_s, C.cast(arrays[dst_s], L.c_void_pp))
-            q8, sc = self._quantize_rows_e4m3(self.lm_head.weight.detach())
-            w.lm_head8, w.lm_head_s = P(q8).data_ptr(), P(sc).data_ptr()
-        w.norm_w = P(self.model.norm.weight).data_ptr()
-        w.lm_head = P(self.lm_head.weight).data_ptr()
-        w.stream_emb = P(self.stream_emb.weight).data_ptr()
-        # rotary tables exactly as transformers computes them (modeling_qwen2.py:91-103,110-121): f32 on the host
-        theta = float(cfg.get("rope_theta", 10000.0))
-        inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
-        fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
-        cos, sin = P(fr.cos().to(dev)), P(fr.sin().to(dev))
-        w.rope_cos, w.rope_sin, w.rope_max_pos = cos.data_ptr(), sin.data_ptr(), max_pos
-        self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv)
+        self._packed = pack_qwen2_weights(self.model, self.lm_head.weight, self.stream_emb.weight, self.cfg, self.num_stream,
+                                          fp8=self._fp8_decode, max_positions=max_positions)
         return self._packed
 
     def _workspace(self, B, T, max_ctx=0):
@@ -328,6 +339,25 @@ class ParallelLLM(nn.Module):
             pad_only = bool(((~m[1:]).sum(-1) == 1).all() and (~m[1:, 0]).all()) if self.num_stream > 1 else True
             self._allowed[name] = (iv.to(self.device).contiguous(), pad_only)
         return self._allowed[name]
+
+    def _stream_intervals(self, name: str):
+        """Allowed id runs of EVERY stream of a mask buffer as a device int32 [S, n_iv, 2] table (unused slots lo == hi): the form
+        afhip_sample_topk takes, one row of the modality mask (lm/parallel.py:557-568) per stream."""
+        key = ("streams", name)
+        if key not in self._allowed:
+            m = getattr(self, f"{name}_mask")[0, 0].cpu()
+            runs = []
+            for srow in m:
+                ok = (~srow).to(torch.int8)
+                d = torch.diff(torch.cat([torch.zeros(1, dtype=torch.int8), ok, torch.zeros(1, dtype=torch.int8)]))
+                runs.append(list(zip((d == 1).nonzero().flatten().tolist(), (d == -1).nonzero().flatten().tolist())))
+            n_iv = max(1, max(len(r) for r in runs))
+            t = torch.zeros((len(runs), n_iv, 2), dtype=torch.int32)
+            for i, r in enumerate(runs):
+                for j, (lo, hi) in enumerate(r):
+                    t[i, j, 0], t[i, j, 1] = lo, hi
+            self._allowed[key] = t.to(self.device).contiguous()
+        return self._allowed[key]
 
     @torch.no_grad()
     def _embed(self, input_ids, kwargs):
@@ -416,14 +446,59 @@ class ParallelLLM(nn.Module):
                                         L.dtype_code(self.dtype), L.ptr(am), am.numel(), L.stream_ptr()))
         return tok
 
+    @torch.no_grad()
+    def _topk_probs(self, logits_f32: torch.Tensor, allowed: torch.Tensor, topk: int, temperature: float,
+                    cfg_logits: Optional[torch.Tensor] = None, cfg: float = 1.0, model_dtype=None, u: Optional[torch.Tensor] = None):
+        """afhip_sample_topk over rows [n, V] (f32): (topk ids [n,k] int32, mixed logits [n,k], probabilities [n,k], drawn ids [n] | None).
+        `allowed` [n, n_iv, 2] int32 id intervals per row; cfg_logits / cfg: the guidance mix of lm/parallel.py:489-492."""
+        lib = L.lib()
+        n, V = logits_f32.shape
+        dev = logits_f32.device
+        idx = torch.empty((n, topk), dtype=torch.int32, device=dev)
+        val = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        prob = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        tok = torch.empty(n, dtype=torch.int64, device=dev) if u is not None else None
+        a = L.SampleArgs()
+        a.logits, a.cfg_logits, a.cfg = logits_f32.data_ptr(), (cfg_logits.data_ptr() if cfg_logits is not None else None), float(cfg)
+        a.rows, a.ld, a.allowed, a.n_iv, a.k = n, logits_f32.stride(0), allowed.data_ptr(), allowed.shape[1], int(topk)
+        a.temperature = float(temperature)
+        a.model_dtype = L.dtype_code(model_dtype if model_dtype is not None else self.dtype)
+        a.topk_idx, a.topk_val, a.topk_prob = idx.data_ptr(), val.data_ptr(), prob.data_ptr()
+        a.u, a.token = (u.data_ptr() if u is not None else None), (tok.data_ptr() if tok is not None else None)
+        L.check(lib.afhip_sample_topk(C.byref(a), L.stream_ptr()))
+        return idx, val, prob, tok
+
     def _logits_to_token(self, logits, temperature, topk):
-        """lm/parallel.py:599-608."""
+        """lm/parallel.py:599-608 on masked logits [B,T,S,V] (any float dtype): greedy argmax, or top-k -> softmax(/T) -> draw.
+        The draw is the inverse CDF at one torch uniform per row (torch.multinomial's distribution); `self._sampler`, when set
+        (tests), receives (topk ids [B,T,S,k], probabilities) and returns the inner indices instead."""
         if temperature == 0:
             return logits.argmax(-1)
-        topk_values, topk_indices = torch.topk(logits, topk)
-        probs = torch.softmax(topk_values.float() / temperature, dim=-1)
-        inner = torch.multinomial(probs.flatten(end_dim=-2), num_samples=1).view(probs[..., :1].size())
-        return torch.gather(topk_indices, -1, inner).squeeze(-1)
+        shp = logits.shape[:-1]
+        rows = logits.reshape(-1, logits.shape[-1]).float().contiguous()
+        whole = torch.tensor([[[0, rows.shape[1]]]], dtype=torch.int32, device=rows.device).expand(rows.shape[0], 1, 2).contiguous()
+        sampler = getattr(self, "_sampler", None)
+        u = None if sampler is not None else torch.rand(rows.shape[0], device=rows.device)
+        idx, val, prob, tok = self._topk_probs(rows, whole, topk, temperature, model_dtype=torch.float32, u=u)
+        if sampler is not None:
+            inner = sampler(idx.view(*shp, topk), prob.view(*shp, topk)).to(rows.device).long().view(-1, 1)
+            tok = torch.gather(idx.long(), 1, inner).squeeze(1)
+        return tok.view(*shp)
+
+    @torch.no_grad()
+    def _prepare_cfg_cache(self, cache: "KVCache") -> "KVCache":
+        """lm/parallel.py:610-644: the unconditional half of classifier-free guidance -- a cache of the same length built from
+        all-pad ids (zero embeddings) -- stacked under the conditional one along the batch axis."""
+        B, length = cache.batch, cache.get_seq_length()
+        zeros = torch.zeros((B, length, self.num_stream), dtype=torch.int64, device=self.device)
+        _, cfg_cache = self._forward_hidden(ops.embed_sum(zeros, self.model.embed_tokens.weight), self.new_cache(B, cache.cap))
+        both = self.new_cache(2 * B, cache.cap)
+        for name in ("k", "v"):
+            dst, a, b = getattr(both, name), getattr(cache, name), getattr(cfg_cache, name)
+            dst[:, :B, :, :length] = a[:, :, :, :length]
+            dst[:, B:, :, :length] = b[:, :, :, :length]
+        both.length = length
+        return both
 
     @torch.no_grad()
     def _greedy_device_loop(self, modality_token, cache: KVCache, modality: str, max_step: int, poll: int = 16):
@@ -439,14 +514,34 @@ class ParallelLLM(nn.Module):
         prev = modality_token[:, 0, 0].to(self.device).contiguous().clone()
         out_tokens = torch.zeros((max_step, B), dtype=torch.int64, device=self.device)
         finished = torch.full((B,), -1, dtype=torch.int32, device=self.device)
+        # loop state on the device (afhip_decode_state.seq_pos / step_counter): nothing position-dependent is baked into kernel
+        # arguments, so ONE captured hipGraph of a step serves every token
+        seq_pos = torch.full((B,), T0, dtype=torch.int32, device=self.device)
+        step_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
         st = L.DecodeState()
         st.prev_token, st.out_tokens, st.finished_at = prev.data_ptr(), out_tokens.data_ptr(), finished.data_ptr()
         st.allowed, st.n_iv, st.eos_id, st.eot_id = iv.data_ptr(), iv.shape[0], self.eos_token_id, self.eot_token_id
+        st.seq_pos, st.step_counter = seq_pos.data_ptr(), step_counter.data_ptr()
         ws = self._workspace(B, 1, cache.cap)
         cs = cache.struct()
+        max_pos = T0 + max_step - 1                      # largest position this loop can append at
+
+        def one_step():
+            L.check(lib.afhip_llm_decode_step(C.byref(pk.w), C.byref(cs), C.byref(st), B, max_pos, 0, L.ptr(ws), ws.numel(), L.stream_ptr()))
+
+        use_graph = os.environ.get("AFHIP_DECODE_GRAPH", "1") != "0" and max_step >= 4
+        graph = None
         n_done = max_step
         for step in range(max_step):
-            L.check(lib.afhip_llm_decode_step(C.byref(pk.w), C.byref(cs), C.byref(st), B, T0 + step, step, L.ptr(ws), ws.numel(), L.stream_ptr()))
+            if use_graph and step == 1:
+                # step 0 ran eagerly (first-use set-up of the kernels happens outside the capture); capture step 1 once, replay it
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    one_step()
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
             if (step + 1) % poll == 0 or step == max_step - 1:
                 f = finished.cpu()
                 if bool((f >= 0).all()):
@@ -499,14 +594,39 @@ class ParallelLLM(nn.Module):
             hypos, finish_idx, cache = self._greedy_device_loop(modality_token, cache, modality, this_config["max_step"])
             prev_token = hypos[:, -1:, :].clone()
         else:
+            # general branch (lm/parallel.py:472-513): sampling, classifier-free guidance, or streams that carry real tokens.
+            # Per step: embed -> one position through the stack -> lm_head on all S streams -> ONE kernel that applies the
+            # guidance mix, the modality mask (as per-stream id intervals), top-k, softmax(/T) and the draw.
+            lib = L.lib()
+            nb = cache.batch                                   # num_hypo
             if cfg > 1:
-                raise NotImplementedError("classifier-free guidance decoding (lm/parallel.py:472-492,610-644) is the audio-output path: not built yet")
+                cache = self._prepare_cfg_cache(cache)
+            S, V, H = self.num_stream, self.lm_head.weight.shape[0], self.cfg["hidden_size"]
+            allowed = self._stream_intervals(modality)[None].expand(nb, -1, -1, -1).reshape(nb * S, -1, 2).contiguous()
+            temperature, topk = this_config["temperature"], this_config["topk"]
+            sampler = getattr(self, "_sampler", None)
             hyp_list = []
-            finish_idx = torch.ones(cache.batch).long().to(device) * -1
+            finish_idx = torch.ones(nb).long().to(device) * -1
             prev_token = modality_token
             for step in range(this_config["max_step"]):
-                logits, cache = self._step(input_ids=prev_token, past_key_values=cache, mask=modality_mask)
-                prev_token = self._logits_to_token(logits, temperature=this_config["temperature"], topk=this_config["topk"])
+                if cfg > 1:
+                    prev_token = prev_token.tile(2, 1, 1)
+                nrow = prev_token.shape[0]
+                hid, cache = self._forward_hidden(ops.embed_sum(prev_token, self.model.embed_tokens.weight), cache)
+                logits = torch.empty((nrow * S, V), dtype=torch.float32, device=device)
+                ws = torch.empty(nrow * S * H * hid.element_size() + 256, dtype=torch.uint8, device=device)
+                L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hid), nrow, S, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+                cond, uncond = (logits[: nb * S], logits[nb * S:]) if cfg > 1 else (logits, None)
+                if temperature == 0:
+                    idx, _, _, _ = self._topk_probs(cond, allowed, 1, 1.0, cfg_logits=uncond, cfg=cfg)
+                    tok = idx[:, 0].long()
+                else:
+                    u = None if sampler is not None else torch.rand(nb * S, device=device)
+                    idx, _, prob, tok = self._topk_probs(cond, allowed, topk, temperature, cfg_logits=uncond, cfg=cfg, u=u)
+                    if sampler is not None:
+                        inner = sampler(idx.view(nb, 1, S, topk), prob.view(nb, 1, S, topk)).to(device).long().view(-1, 1)
+                        tok = torch.gather(idx.long(), 1, inner).squeeze(1)
+                prev_token = tok.view(nb, 1, S)
                 hyp_list.append(prev_token)
                 finish_here = torch.logical_and(
                     torch.logical_or(prev_token[:, 0, 0] == self.eot_token_id, prev_token[:, 0, 0] == self.eos_token_id),
@@ -516,6 +636,8 @@ class ParallelLLM(nn.Module):
                     break
             finish_idx = torch.where(finish_idx == -1, step, finish_idx)
             hypos = torch.cat(hyp_list, dim=1)
+            if cfg > 1:
+                cache.batch_select_indices(torch.arange(nb, device=device))
 
         # (5) "prefill the last token" so that a following segment continues from it (:523-526)
         prev_token = prev_token.clone()

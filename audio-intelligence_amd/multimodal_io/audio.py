@@ -115,3 +115,63 @@ class ContinuousAudioIO(AbsIO):
 
     def feature_dim(self) -> int:
         return self.d_model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Audio-OUTPUT token bookkeeping.  The reference's DiscreteAudioIO (audio.py:68-870) wraps codec / SSL models that
+# must be fetched from the network; what the decode loop needs from it is the vocabulary / stream-interval contract and the
+# delay (de)interleave of the 8 codebook streams.  The waveform itself (X-codec decode, audio.py:544-596) is outside the path.
+def delay_interleave(codes: torch.Tensor, pad_ids) -> torch.Tensor:
+    """audio.py:758-782: stream n is delayed by n frames; [B, T, N] -> [B, T + N - 1, N], vacated slots hold the stream's pad id
+    (the first id of its interval)."""
+    B, T, N = codes.shape
+    out = torch.as_tensor(list(pad_ids), dtype=torch.long, device=codes.device).tile(B, T + N - 1, 1)
+    for n in range(N):
+        out[:, n:n + T, n] = codes[:, :, n]
+    return out
+
+
+def delay_deinterleave(codes: torch.Tensor) -> torch.Tensor:
+    """audio.py:785-808: inverse of delay_interleave; [B, T, N] -> [B, T - N + 1, N]."""
+    _, T, N = codes.shape
+    T0 = T - N + 1
+    return torch.stack([codes[:, n:n + T0, n] for n in range(N)], dim=-1)
+
+
+class DiscreteAudioTokenIO(AbsIO):
+    """The part of DiscreteAudioIO the LLM side depends on: `num_stream` codebook streams of `codebook_size` entries (+1 pad id
+    each, audio.py:301-414), their vocabulary and stream intervals, and `decode_batch` up to the codec call: unified-vocabulary
+    ids [B, T, S] -> de-interleaved codec codes [B, T - S + 1, S] (audio.py:494-541).  No codec model: `decode_batch` returns codes."""
+
+    def __init__(self, n_stream: int = 8, codebook_size: int = 1024, delay_interleave: bool = True):
+        super().__init__(modality="audio", is_discrete=True)
+        self.n_stream, self.codebook_size, self.delay = n_stream, codebook_size, delay_interleave
+        self._stream_intervals = None
+
+    def num_stream(self):
+        return self.n_stream
+
+    def get_vocabulary(self):
+        return [f"<audio_{i}>" for i in range(self.n_stream * (self.codebook_size + 1))]
+
+    def get_stream_interval(self):
+        w = self.codebook_size + 1
+        return [(s * w, (s + 1) * w) for s in range(self.n_stream)]
+
+    def set_vocab_offset(self, intervals):
+        """absolute intervals of the unified vocabulary (vocab_intervals["discrete_audio"], ualm_job.py:96-104)"""
+        self._stream_intervals = [tuple(iv) for iv in intervals]
+
+    def copy_for_worker(self):
+        return self
+
+    def decode_batch(self, codes: torch.Tensor, lengths: torch.Tensor):
+        if codes.dim() != 3:
+            raise ValueError(f"Expected 3D token tensor [batch, time, n_streams], got {codes.dim()}D")
+        if self.delay:
+            codes = delay_deinterleave(codes)
+            lengths = lengths - self.num_stream() + 1
+        codes = codes.clone()
+        for s, (start, _) in enumerate(self.get_stream_interval()):
+            codes[..., s] -= start + 1                  # ids relative to the IO's own vocabulary; slot 0 of a stream is its pad
+        return codes, lengths

@@ -377,3 +377,12 @@ def merge_input_ids_with_audio_features(audio_features, num_audio_tokens, inputs
     emb = ops.gather_rows(inputs_embeds.contiguous().view(-1, H), feats.view(-1, H), plan_d, B * M).view(B, M, H)
     return (emb, torch.from_numpy(fmask).to(device=dev, dtype=attention_mask.dtype), final_labels,
             torch.from_numpy(pos).to(dev), torch.from_numpy(fids).to(device=dev, dtype=input_ids.dtype))
+
+
+def __getattr__(name):
+    # `Qwen2AudioForConditionalGeneration` lives in qwen2_audio_generation.py (it builds on the LLM side) but is importable from
+    # here, where the reference defines it (modeling_whisper.py:855)
+    if name == "Qwen2AudioForConditionalGeneration":
+        from .qwen2_audio_generation import Qwen2AudioForConditionalGeneration
+        return Qwen2AudioForConditionalGeneration
+    raise AttributeError(name)

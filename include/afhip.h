@@ -191,6 +191,13 @@ typedef struct {
      * (stores -> s_waitcnt vmcnt(0) -> barrier -> agent-scope release -> relaxed agent atomic add); the workgroup that draws the
      * last ticket acquires and merges all ranges in the same order as the second pass would: bit-identical output. */
     int* split_ticket;
+    /* key_split > 0 only: per-sequence context lengths read ON THE DEVICE.  seq_pos [B] int32 = position of the token being
+     * generated for each sequence: sequence b attends to keys [0, seq_pos[b]] (its Tk is seq_pos[b] + 1), the fused RoPE uses row
+     * seq_pos[b] of the FULL cos/sin tables (rope_cos / rope_sin then point at row 0) and the append lands at that slot.  `Tk` is
+     * then only an upper bound that sizes the grid; key-range workgroups beyond a sequence's context exit.  This is what lets
+     * one captured hipGraph of a decode step be replayed for every token (nothing position-dependent is baked into kernel
+     * arguments) and what a ragged batch (AF3 generate() with left / right padded prompts) needs. */
+    const int32_t* seq_pos;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 
@@ -271,6 +278,13 @@ size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, int T, int m
 int afhip_llm_forward(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
                       void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One new token per sequence with PER-SEQUENCE positions held on the device: seq_pos [B] int32 = cache slot / RoPE position of each
+ * sequence's token (sequence b then attends to keys [0, seq_pos[b]]); max_pos >= every seq_pos[b] bounds them for the host-side
+ * range checks and the grid.  Serves ragged batches (AF3 generate() over left / right padded prompts,
+ * modeling_whisper.py:1250-1318) and graph replay (afhip_decode_state.seq_pos).  x [B, hidden], hidden_out [B, hidden]. */
+int afhip_llm_forward_ragged(const afhip_llm_weights* w, const void* x, int B, const int32_t* seq_pos, int max_pos,
+                             afhip_kv_cache* cache, void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* logits[r, s, :] = (hidden[r] + (s ? stream_emb[s] : 0)) . lm_head^T for s < n_s (lm/parallel.py:588-592); f32 out. */
 int afhip_lm_head(const afhip_llm_weights* w, const void* hidden, int rows, int n_s, float* logits, void* workspace,
                   size_t workspace_bytes, void* stream);
@@ -285,6 +299,30 @@ size_t afhip_masked_argmax_workspace_bytes(int rows);
 int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* allowed, int n_iv, int64_t* token,
                         int logits_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sampling branch of the decode loop: top-k -> softmax(values / temperature) -> draw (lm/parallel.py:603-608), with the
+ * classifier-free-guidance mix and re-mask of inference_segment folded in (lm/parallel.py:489-492:
+ * logits * cfg + cfg_logits * (1 - cfg) as three separately rounded tensor ops, then the modality mask).  One row per
+ * (sequence, stream).  The reference draws with torch.multinomial; here the draw is the inverse CDF at a caller-supplied uniform
+ * u[r] (same distribution, no RNG stream to reproduce); leave u / token NULL to get only the top-k set and its probabilities. */
+typedef struct {
+    const float* logits;      /* [rows, ld] f32: lm_head output of the conditional half */
+    const float* cfg_logits;  /* [rows, ld] f32 of the unconditional (all-pad cache) half, or NULL: no guidance */
+    float cfg;                /* guidance weight (conf/inference.yaml:7), used when cfg_logits != NULL */
+    int rows, ld;
+    const int32_t* allowed;   /* [rows][n_iv][2] half-open id intervals the row may emit (its stream's row of the modality mask;
+                                 unused slots lo == hi) */
+    int n_iv;
+    int k;                    /* 1..64 (conf/inference.yaml:6: 20) */
+    float temperature;        /* > 0 */
+    int model_dtype;          /* AFHIP_BF16: logits and every intermediate of the mix are rounded to bf16, as the reference's tensors are */
+    int32_t* topk_idx;        /* [rows, k] out (may be NULL): ids by descending value, ties by ascending id */
+    float* topk_val;          /* [rows, k] out (may be NULL): the mixed, masked logits at those ids */
+    float* topk_prob;         /* [rows, k] out (may be NULL): softmax(val / temperature) */
+    const float* u;           /* [rows] uniforms in [0,1), or NULL */
+    int64_t* token;           /* [rows] out, or NULL: topk_idx[first j with cdf_j > u] */
+} afhip_sample_args;
+int afhip_sample_topk(const afhip_sample_args* args, void* stream);
+
 /* One greedy decode step for B sequences entirely on device: embed prev token (stream 0 = token, others pad),
  * forward 1 position, lm_head on stream 0, masked argmax, append to out_tokens[step], update finished flags
  * (eos/eot, lm/parallel.py:503-513).  No host sync. */
@@ -295,6 +333,12 @@ typedef struct {
     const int32_t* allowed;  /* [n_iv,2] */
     int n_iv;
     int eos_id, eot_id;
+    /* Optional, both or neither (NULL = the host scalars `pos` / `step` of the call are used): device-resident loop state, so that
+     * ONE captured hipGraph of afhip_llm_decode_step can be replayed for every token.  seq_pos [B]: position of the token each
+     * sequence appends next (the step increments it); step_counter [1]: row of out_tokens to write (the step increments it).
+     * `pos` is then the upper bound of seq_pos over the replays (checked against the cache capacity and the RoPE table). */
+    int32_t* seq_pos;
+    int32_t* step_counter;
 } afhip_decode_state;
 int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache* cache, afhip_decode_state* st, int B, int pos,
                           int step, void* workspace, size_t workspace_bytes, void* stream);

@@ -238,3 +238,26 @@ def inference_segment(batch: dict, sd, cfg, enc_sd, enc_cfg, intervals, max_step
     if return_margins:
         return hyp, modality, margins
     return hyp, modality
+
+
+# ------------------------------------------------------------------------------------------- sampling / guidance
+def cfg_mix(logits: torch.Tensor, cfg_logits: torch.Tensor, cfg: float, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """lm/parallel.py:489-492: `logits * cfg + cfg_logits * (1 - cfg)` as separate tensor ops (each rounds to the tensors' dtype),
+    then the modality mask again."""
+    out = logits * cfg + cfg_logits * (1 - cfg)
+    if mask is not None:
+        out = out.masked_fill(mask, float("-inf"))
+    return out
+
+
+def topk_probs(logits: torch.Tensor, temperature: float, topk: int):
+    """lm/parallel.py:603-604: (topk_values, topk_indices, softmax(topk_values / temperature))."""
+    vals, idx = torch.topk(logits, topk)
+    return vals, idx, torch.softmax(vals / temperature, dim=-1)
+
+
+def inverse_cdf_pick(probs: torch.Tensor, idx: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """The draw the HIP path uses in place of torch.multinomial (same distribution): first j with cumsum(p)[j] > u."""
+    cdf = torch.cumsum(probs.float(), dim=-1)
+    j = (cdf <= u.unsqueeze(-1)).sum(-1).clamp(max=probs.shape[-1] - 1)
+    return torch.gather(idx, -1, j.unsqueeze(-1)).squeeze(-1)

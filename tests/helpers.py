@@ -10,6 +10,20 @@ from oracle import fixtures_common as fc
 from audio_intelligence_amd.utils import synthetic as syn
 
 GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cpu_threads():
+    """CPU threads this process may really use: the scheduler affinity capped by the cgroup CPU quota (a GPU box shows every core
+    of the host in the affinity mask but grants a 16-CPU share; oversubscribing it makes the oracle crawl)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        n = min(n, 16)
+    return max(1, min(n, 64))
 _cache = {}
 
 

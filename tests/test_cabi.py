@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from audio_intelligence_amd import _lib as L
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for cname, cls in (("afhip_gemm_args", L.GemmArgs), ("afhip_attn_args", L.AttnArgs), ("afhip_encoder_weights", L.EncoderWeights),
-                       ("afhip_llm_weights", L.LlmWeights), ("afhip_kv_cache", L.KvCache), ("afhip_decode_state", L.DecodeState)):
+                       ("afhip_llm_weights", L.LlmWeights), ("afhip_kv_cache", L.KvCache), ("afhip_decode_state", L.DecodeState), ("afhip_sample_args", L.SampleArgs)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", src).group(1)
         fields = []
         for decl in body.split(";"):
@@ -44,6 +44,39 @@ def test_struct_layouts_match_header():
             for part in decl.split(","):
                 fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
         assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_struct_offsets_and_sizes_match_the_c_compiler(tmp_path):
+    """Types, offsets and sizes, not just names: a C program compiled against include/afhip.h prints offsetof / sizeof of every
+    field of every struct that crosses the boundary; the ctypes mirror must agree byte for byte."""
+    import shutil
+    import subprocess
+    from audio_intelligence_amd import _lib as L
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler on this host")
+    structs = (("afhip_gemm_args", L.GemmArgs), ("afhip_attn_args", L.AttnArgs), ("afhip_encoder_weights", L.EncoderWeights),
+               ("afhip_llm_weights", L.LlmWeights), ("afhip_kv_cache", L.KvCache), ("afhip_decode_state", L.DecodeState),
+               ("afhip_sample_args", L.SampleArgs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in structs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu %zu\\n", offsetof({cname}, {fname}), sizeof((({cname}*)0)->{fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-std=c11", "-o", str(exe), str(src)], check=True)
+    got = dict()
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        parts = ln.split()
+        got[parts[0]] = tuple(int(x) for x in parts[1:])
+    for cname, cls in structs:
+        assert got[cname] == (C.sizeof(cls),), f"sizeof({cname}): C {got[cname]} vs ctypes {C.sizeof(cls)}"
+        for fname, ftype in cls._fields_:
+            fd = getattr(cls, fname)
+            assert got[f"{cname}.{fname}"] == (fd.offset, fd.size), f"{cname}.{fname}: C (offset, size) {got[f'{cname}.{fname}']} vs ctypes {(fd.offset, fd.size)}"
 
 
 def test_argument_validation_returns_error_not_abort():

@@ -262,7 +262,7 @@ def test_llm_7b_widths_bf16_batch_of_8_invariance_and_oracle():
         assert torch.equal(l1[0], logits[b]), f"clip {b}: prefill logits differ between B=1 and B=8"
         assert t1[0].tolist() == toks[b].tolist(), f"clip {b}: B=1 ids {t1[0].tolist()} != batched ids {toks[b].tolist()}"
 
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(H.cpu_threads())
     ref_emb = F.embedding(ids.cpu(), sd["model.embed_tokens.weight"]).sum(dim=2)
     ref_emb[:, start:start + 750] = F.linear(feats.float(), sd["adaptor.continuous_audio.weight"], sd["adaptor.continuous_audio.bias"])
     e_err = (emb.float().cpu() - ref_emb).abs()

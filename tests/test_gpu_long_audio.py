@@ -100,7 +100,7 @@ def test_llm_forward_15k_prompt_7b_widths_bf16():
     hid, cache = model._forward_hidden(x.to(DEV), model.new_cache(1, T + 64))
     assert cache.get_seq_length() == T
     rows = _sample_rows(T, n_rand=96, tail=32, seed=1)
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(H.cpu_threads())
     ref, _ = oracle.qwen2.forward(x.float(), sd, cfg, last_layer_rows=rows)
     err = (hid[0, rows].float().cpu() - ref[0]).abs()
     print(f"T={T} 7B widths 1 layer: sampled hidden err max {float(err.max()):.4f} mean {float(err.mean()):.5f}")

@@ -204,3 +204,31 @@ def test_to_device_casts_floats_only():
     o = inf.to_device(d, "cpu", dtype=torch.bfloat16)
     assert o["seqs"].dtype == torch.long and o["feats"][0].dtype == torch.bfloat16 and o["feats"][1].dtype == torch.bfloat16
     assert o["keys"] == [("a", "b", "c")] and o["n"] == 3
+
+
+def test_af3_prepare_inputs_for_generation_known_answers():
+    """The three input-slicing rules + on-the-fly position ids of Qwen2AudioForConditionalGeneration.prepare_inputs_for_generation
+    (modeling_whisper.py:1250-1318) against answers captured from the reference function (oracle/make_golden_af3.py)."""
+    import json
+    import os
+    import torch
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import Qwen2AudioForConditionalGeneration as Q
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_af3.json")) as f:
+        g = json.load(f)
+
+    class Past:
+        def __init__(self, n):
+            self.n = n
+
+        def get_seq_length(self):
+            return self.n
+
+    fake = type("S", (), {"audio_token_index": g["audio_token_index"]})()
+    for c in g["prepare_inputs"]:
+        past = None if c["past"] is None else Past(c["past"])
+        r = Q.prepare_inputs_for_generation(fake, torch.tensor(c["input_ids"]), past_key_values=past, input_features=(object() if c["feat"] else None),
+                                            attention_mask=(torch.tensor(c["mask"]) if c.get("mask") is not None else None))
+        e = c["expect"]
+        assert r["input_ids"].tolist() == e["input_ids"], c["name"]
+        assert (None if r["position_ids"] is None else r["position_ids"].tolist()) == e["position_ids"], c["name"]
+        assert (None if r["attention_mask"] is None else r["attention_mask"].tolist()) == e["attention_mask"], c["name"]
