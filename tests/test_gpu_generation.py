@@ -128,7 +128,8 @@ def test_sample_topk_kernel_vs_oracle(dt):
     g = torch.Generator().manual_seed(5)
     lg = (torch.randn(rows, V, generator=g) * 2).to(dt)
     cl = (torch.randn(rows, V, generator=g) * 2).to(dt)
-    lg[0, 100] = lg[0, 200] = lg[0].max() + 1                       # a tie at the top: lower id first
+    lg[0, 100] = lg[0, 200] = 10.0                                   # a tie at the top of the MIXED values: lower id first
+    cl[0, 100] = cl[0, 200] = -10.0
     iv = torch.zeros((rows, 2, 2), dtype=torch.int32)
     for r in range(rows):
         iv[r, 0] = torch.tensor([50 + 10 * r, 1500])
