@@ -15,6 +15,7 @@
 // and SwiGLU can instead be the EPILOGUE of the gate/up GEMM (`swiglu_out`): a NT = 4 workgroup owns exactly one 64-row
 // gate/up block pair, so the K-slice combine emits silu(gate) * up straight into the [M, N/2] activation (modeling_qwen2.py:46-48).
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef SKINNY_DEPTH
 #define SKINNY_DEPTH 2      /* K steps in flight per wave, NT >= 2 (3 costs the second workgroup per CU: measured slower) */
@@ -42,6 +43,7 @@ struct SkinnyP {
     int out_f32;
     float norm_eps;
     int swiglu_out;
+    int a_rows;      // ALDS: rows of the activation image kept in LDS (8 or 16, >= M)
     int tile_rows;   // weight rows per 16-wide MFMA tile that carry work (<= 16): narrow outputs are cut into ceil(N / CUs)-row shares so every CU streams the same bytes
 };
 
@@ -76,7 +78,12 @@ template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
 // step set and pushed skinny_kernel<*, 1, 4, *> into scratch
 template <int NT, int MT, int XM> struct StepRegs { u32x4 w0[NT], w1[NT], a0[MT], a1[MT], x0[XM], x1[XM], n0, n1; };
 
-template <typename T, int NT, int MT, int AMODE, int NW = 8>
+// ALDS (bf16, MT == 1, K small enough): the activations are staged ONCE per workgroup into LDS -- RMSNorm gain applied, row
+// sums of squares taken on the way -- in the order the MFMA A operand wants them ([K step][16-B half][q][row]: a wave reads
+// 16 B per lane at consecutive addresses, conflict-free), so the K loop issues weight loads only.  Without it every wave re-reads
+// its activation (and gain) fragments from L2 next to each weight fragment: as many vector-memory instructions again as the
+// weight stream itself for NT = 1, which is what held the 3584-wide projections at 4 TB/s while NT = 4 reached 6.
+template <typename T, int NT, int MT, int AMODE, int NW = 8, bool ALDS = false>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     constexpr int SZ = sizeof(T);
     constexpr int KS = Step<T>::K;
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NT][MT][64 lanes][4]
     float* red_ss = red + NW * NT * MT * 256;                      // [8 waves][MT][16] row sums of squares (A_RMSNORM)
+    char* aimg = reinterpret_cast<char*>(red_ss + NW * MT * 16);   // ALDS: [K / 64][2][4][a_rows] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
@@ -118,6 +126,39 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     for (int b = 0; b < MT; ++b) ss[b] = 0.f;
 
     const int nsteps = p.K / KS;
+    const int RM = p.a_rows;
+    auto stage_a = [&]() {
+        if constexpr (ALDS) {
+            static_assert(sizeof(T) == 2 && MT == 1 && AMODE != A_SWIGLU, "ALDS: bf16, one row tile, plain / RMSNorm A");
+            // wave w stages rows w, w + NW, ...: 16-B chunk cc of a row covers k = 8 cc .. 8 cc + 7 = step cc >> 3, q = (cc >> 1) & 3, half cc & 1
+            for (int m = wave; m < RM; m += NW) {
+                const bool real = m < p.M;
+                const char* src = p.A + (long long)m * p.lda * SZ;
+                float sq = 0.f;
+                for (int cc = lane; cc < p.K / 8; cc += 64) {
+                    u32x4 v = real ? ld16(src + cc * 16) : u32x4{0u, 0u, 0u, 0u};
+                    if constexpr (AMODE == A_RMSNORM) {
+                        const u32x4 g = ld16(p.norm_w + cc * 16);
+                        float f[8];
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = elem<T>(v, e);
+                            sq += x * x;
+                            f[e] = x * elem<T>(g, e);
+                        }
+                        v = pack<T>(f);
+                    }
+                    st16(aimg + (cc >> 3) * (RM * 128) + (cc & 1) * (RM * 64) + ((((cc >> 1) & 3) * RM + m) << 4), v);
+                }
+                if constexpr (AMODE == A_RMSNORM) {
+                    sq = wave_sum(sq);
+                    if (lane == 0) red_ss[m] = sq;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    const int a_lane = (q * RM + (c16 & (RM - 1))) << 4;          // ALDS: this lane's 16 B inside a [q][row] plane (rows >= a_rows alias: dropped later)
 
     constexpr int XM = AMODE == A_SWIGLU ? MT : 1;
     typedef StepRegs<NT, MT, XM> Regs;
@@ -134,16 +175,24 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
                 r.a0[t] = ld16(arow[t] + goff); r.a1[t] = ld16(arow[t] + goff + 16);
                 r.x0[t] = ld16(arow[t] + goff + 32 * SZ); r.x1[t] = ld16(arow[t] + goff + 32 * SZ + 16);
             }
+        } else if constexpr (ALDS) {
+            // the activation fragment is read from LDS at consume time (the image may not exist yet when the first steps are issued)
         } else {
 #pragma unroll
             for (int t = 0; t < MT; ++t) { r.a0[t] = ld16(arow[t] + koff); r.a1[t] = ld16(arow[t] + koff + 16); }
             if constexpr (AMODE == A_RMSNORM) { r.n0 = ld16(p.norm_w + koff); r.n1 = ld16(p.norm_w + koff + 16); }
         }
     };
-    auto consume = [&](Regs& r) {
+    auto consume = [&](Regs& r, int s) {
+        if constexpr (ALDS) {
+            r.a0[0] = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 128) + a_lane);
+            r.a1[0] = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 128) + RM * 64 + a_lane);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if constexpr (AMODE == A_RMSNORM) {
+            if constexpr (ALDS) {
+                // staged: gain already applied, squares already summed
+            } else if constexpr (AMODE == A_RMSNORM) {
                 float f0[HN], f1[HN];
 #pragma unroll
                 for (int e = 0; e < HN; ++e) {
@@ -193,13 +242,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
             sx[d] = wave + NW * d;
             if (sx[d] < nsteps) issue(sx[d], r[d]);
         }
+        stage_a();      // ALDS: the activation image is built while the first weight fragments are already in flight
         bool more = sx[0] < nsteps;
         while (more) {
             more = false;
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 if (sx[d] < nsteps) {
-                    consume(r[d]);
+                    consume(r[d], sx[d]);
                     sx[d] += NW * DEPTH;
                     if (sx[d] < nsteps) { issue(sx[d], r[d]); more = true; }
                 }
@@ -213,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<f32x4*>(red + ((((wave * NT + nt) * MT + mt) * 64 + lane) << 2)) = acc[nt][mt];
-    if constexpr (AMODE == A_RMSNORM) {
+    if constexpr (AMODE == A_RMSNORM && !ALDS) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v = ss[mt];
@@ -243,8 +293,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
                 if (ng + 32 < p.N + 1 && m < p.M) {
                     if constexpr (AMODE == A_RMSNORM) {
                         float sq = 0.f;
+                        if constexpr (ALDS) sq = red_ss[mrow];
+                        else {
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                            for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                        }
                         const float r = rsqrtf(sq / (float)p.K + p.norm_eps);
                         g *= r; u *= r;
                     }
@@ -267,8 +320,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
         if ((ln & 15) < TR && n < p.N && m < p.M) {
             if constexpr (AMODE == A_RMSNORM) {
                 float sq = 0.f;
+                if constexpr (ALDS) sq = red_ss[mrow];
+                else {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                    for (int w = 0; w < NW; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                }
                 v *= rsqrtf(sq / (float)p.K + p.norm_eps);
             }
             if (p.bias) v += to_f32<T>(reinterpret_cast<const T*>(p.bias)[n]);
@@ -282,11 +338,31 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
 // NW = waves that split K inside a workgroup.  The narrow bf16 tiles (NT = 1: q/k/v and o of the decoder, 224-288 workgroups of
 // 7 K steps per wave) can split K over 16 waves (SKINNY_NW1); f32 always keeps 8 (its summation order is part of
 // the bit-exact parity contract).
+constexpr size_t SKINNY_ALDS_MAX = 120 * 1024;   // activation image + K-slice combine must leave the workgroup resident (160 KiB LDS)
+
 template <typename T, int NT, int MT>
 void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
     constexpr int NW = (NT == 1 && sizeof(T) == 2 && MT <= 2) ? SKINNY_NW1 : 8;
     const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(NW * 64);
     const size_t lds = ((size_t)NW * NT * MT * 256 + NW * MT * 16) * sizeof(float);
+    if constexpr (sizeof(T) == 2 && MT == 1) {
+        const size_t img = (size_t)p.a_rows * p.K * 2;
+        static int use = -1;
+        // A/B switch, default OFF for bf16 weights: measured 3.81-3.93 vs 3.63 ms per 7B decode step (the 57-KiB image halves the
+        // workgroups per CU of gate/up, and co-resident workgroups hiding each other's ramp matter more than the saved loads);
+        // the e4m3 kernel, whose K step carries 8 activation / gain loads per 2 NT weight loads, gains 3.5 % and keeps it on
+        if (use < 0) { const char* e = getenv("AFHIP_SKINNY_ALDS"); use = (e && e[0] == '1') ? 1 : 0; }
+        if (use && amode != A_SWIGLU && p.K % 64 == 0 && lds + img <= SKINNY_ALDS_MAX) {
+            static unsigned long long attr_done = 0;
+            if (afhip_first_use_on_device(&attr_done)) {
+                (void)hipFuncSetAttribute((const void*)skinny_kernel<T, NT, MT, A_RMSNORM, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SKINNY_ALDS_MAX);
+                (void)hipFuncSetAttribute((const void*)skinny_kernel<T, NT, MT, A_PLAIN, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SKINNY_ALDS_MAX);
+            }
+            if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM, NW, true>), grid, block, lds + img, s, p);
+            else hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_PLAIN, NW, true>), grid, block, lds + img, s, p);
+            return;
+        }
+    }
     switch (amode) {
         case A_RMSNORM: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_RMSNORM, NW>), grid, block, lds, s, p); break;
         case A_SWIGLU: hipLaunchKernelGGL((skinny_kernel<T, NT, MT, A_SWIGLU, NW>), grid, block, lds, s, p); break;
@@ -339,6 +415,7 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     const bool wide = a->N >= 8192 && mt <= 2;   // NT=4 needs 8*NT*MT KiB of LDS for the K-slice combine
     if (sw_out) AFHIP_CHECK(wide && a->N % 64 == 0 && !a->bias && !a->residual && !a->out_f32, "afhip_gemm_skinny: SWIGLU epilogue needs N >= 8192, N %% 64 == 0, M <= 32, no bias/residual");
     p.swiglu_out = sw_out ? 1 : 0;
+    p.a_rows = a->M <= 8 ? 8 : 16;
     p.tile_rows = 16;
     // narrow outputs (the 3584 / 4608-wide decoder projections): 16-row tiles give 224 or 288 workgroups on 256 CUs -- 12 % of the
     // chip idle, or a second round for 32 of them.  Cut N into one share of ceil(N / CUs) rows per CU instead (14 rows x 256 for

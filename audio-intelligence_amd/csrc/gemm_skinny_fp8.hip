@@ -7,6 +7,7 @@
 // accumulator in the epilogue, next to the fused RMSNorm row scale / SwiGLU epilogue of the bf16 kernel.
 // Reference counterpart: none (BASELINE config 5 "fp8 MFMA GEMMs"); checked against the dequantised weights in f32.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef SKINNY_DEPTH
 #define SKINNY_DEPTH 2      /* K steps in flight per wave, NT >= 2 (3 costs the second workgroup per CU: measured slower) */
@@ -32,6 +33,7 @@ struct SkinnyF8P {
     int out_f32;
     float norm_eps;
     int swiglu_out;
+    int a_rows;      // ALDS: rows of the activation image kept in LDS (8 or 16, >= M)
     int tile_rows;   // weight rows per 16-wide MFMA tile that carry work (<= 16): narrow outputs are cut into ceil(N / CUs)-row shares so every CU streams the same bytes
 };
 
@@ -51,11 +53,14 @@ __device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t v, uint32_t& lo, uint32
 
 template <int NT, int MT> struct StepRegs8 { u32x4 w[NT][2]; u32x4 a[MT][4]; u32x4 n[4]; };
 
-template <int NT, int MT, int AMODE>
+// ALDS: activations staged once per workgroup into LDS in MFMA A-operand order, RMSNorm gain applied and squares summed on the
+// way (gemm_skinny.hip): with e4m3 weights the activation + gain fragments were 8 of the 8 + 2 NT vector loads of a K step.
+template <int NT, int MT, int AMODE, bool ALDS = false>
 __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NT][MT][64 lanes][4]
     float* red_ss = red + 8 * NT * MT * 256;                      // [8 waves][MT][16]
+    char* aimg = reinterpret_cast<char*>(red_ss + 8 * MT * 16);   // ALDS: [K / 128][4][4][a_rows] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
@@ -89,21 +94,66 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     for (int b = 0; b < MT; ++b) ss[b] = 0.f;
 
     const int nsteps = p.K / KS8;
+    const int RM = p.a_rows;
+    auto stage_a = [&]() {
+        if constexpr (ALDS) {
+            static_assert(MT == 1, "ALDS: one row tile");
+            // 16-B chunk cc of a row covers k = 8 cc ..: step cc >> 4, q = (cc >> 2) & 3, chunk-in-lane cc & 3
+            for (int m = wave; m < RM; m += 8) {
+                const bool real = m < p.M;
+                const char* src = p.A + (long long)m * p.lda * 2;
+                float sq = 0.f;
+                for (int cc = lane; cc < p.K / 8; cc += 64) {
+                    u32x4 v = real ? ld16(src + cc * 16) : u32x4{0u, 0u, 0u, 0u};
+                    if constexpr (AMODE == A_RMSNORM) {
+                        const u32x4 g = ld16(p.norm_w + cc * 16);
+                        u32x4 o;
+    #pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const float x0 = bf16_lo(v[d]), x1 = bf16_hi(v[d]);
+                            sq += x0 * x0 + x1 * x1;
+                            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                            bf16x2_t pr;
+                            pr[0] = (bf16)(x0 * bf16_lo(g[d]));
+                            pr[1] = (bf16)(x1 * bf16_hi(g[d]));
+                            o[d] = __builtin_bit_cast(uint32_t, pr);
+                        }
+                        v = o;
+                    }
+                    st16(aimg + (cc >> 4) * (RM * 256) + (cc & 3) * (RM * 64) + ((((cc >> 2) & 3) * RM + m) << 4), v);
+                }
+                if constexpr (AMODE == A_RMSNORM) {
+                    sq = wave_sum(sq);
+                    if (lane == 0) red_ss[m] = sq;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    const int a_lane = (q * RM + (c16 & (RM - 1))) << 4;
     auto issue = [&](int s, StepRegs8<NT, MT>& r) {
         const long long k0 = (long long)s * KS8 + q * 32;          // first of this lane's 32 K elements
 #pragma unroll
         for (int t = 0; t < NT; ++t) { r.w[t][0] = ld16(wrow[t] + k0); r.w[t][1] = ld16(wrow[t] + k0 + 16); }
+        if constexpr (ALDS) {
+            // read from LDS at consume time
+        } else {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r.a[t][c] = ld16(arow[t] + k0 * 2 + c * 16);
-        if constexpr (AMODE == A_RMSNORM) {
+                for (int c = 0; c < 4; ++c) r.a[t][c] = ld16(arow[t] + k0 * 2 + c * 16);
+            if constexpr (AMODE == A_RMSNORM) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r.n[c] = ld16(p.norm_w + k0 * 2 + c * 16);
+                for (int c = 0; c < 4; ++c) r.n[c] = ld16(p.norm_w + k0 * 2 + c * 16);
+            }
         }
     };
-    auto consume = [&](StepRegs8<NT, MT>& r) {
-        if constexpr (AMODE == A_RMSNORM) {
+    auto consume = [&](StepRegs8<NT, MT>& r, int s) {
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r.a[0][c] = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 256) + c * (RM * 64) + a_lane);
+        }
+        if constexpr (AMODE == A_RMSNORM && !ALDS) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -153,13 +203,14 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
             sx[d] = wave + 8 * d;
             if (sx[d] < nsteps) issue(sx[d], r[d]);
         }
+        stage_a();      // ALDS: the activation image is built while the first weight fragments are already in flight
         bool more = sx[0] < nsteps;
         while (more) {
             more = false;
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 if (sx[d] < nsteps) {
-                    consume(r[d]);
+                    consume(r[d], sx[d]);
                     sx[d] += 8 * DEPTH;
                     if (sx[d] < nsteps) { issue(sx[d], r[d]); more = true; }
                 }
@@ -172,7 +223,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<f32x4*>(red + ((((wave * NT + nt) * MT + mt) * 64 + lane) << 2)) = acc[nt][mt];
-    if constexpr (AMODE == A_RMSNORM) {
+    if constexpr (AMODE == A_RMSNORM && !ALDS) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v = ss[mt];
@@ -185,8 +236,11 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     auto row_scale = [&](int mt, int mrow) {
         if constexpr (AMODE == A_RMSNORM) {
             float sq = 0.f;
+            if constexpr (ALDS) sq = red_ss[mrow];
+            else {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+                for (int w = 0; w < 8; ++w) sq += red_ss[(w * MT + mt) * 16 + mrow];
+            }
             return rsqrtf(sq / (float)p.K + p.norm_eps);
         } else {
             return 1.0f;
@@ -238,6 +292,21 @@ template <int NT, int MT>
 void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
     const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(512);
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
+    if constexpr (MT == 1) {
+        const size_t img = (size_t)p.a_rows * p.K * 2;
+        static int use = -1;
+        if (use < 0) { const char* e = getenv("AFHIP_SKINNY_ALDS"); use = (e && e[0] == '0') ? 0 : 1; }     // A/B switch
+        if (use && lds + img <= 120 * 1024) {
+            static unsigned long long attr_done = 0;
+            if (afhip_first_use_on_device(&attr_done)) {
+                (void)hipFuncSetAttribute((const void*)skinny_fp8_kernel<NT, MT, A_RMSNORM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void*)skinny_fp8_kernel<NT, MT, A_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+            }
+            if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_RMSNORM, true>), grid, block, lds + img, s, p);
+            else hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_PLAIN, true>), grid, block, lds + img, s, p);
+            return;
+        }
+    }
     if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_RMSNORM>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((skinny_fp8_kernel<NT, MT, A_PLAIN>), grid, block, lds, s, p);
 }
@@ -272,6 +341,7 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     p.swiglu_out = sw_out ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int amode = a->a_norm_w ? A_RMSNORM : A_PLAIN;
+    p.a_rows = a->M <= 8 ? 8 : 16;
     p.tile_rows = 16;
     int nt_narrow = 1;
     if (!wide && !sw_out) {                 // one equal share of weight rows per CU (gemm_skinny.hip)
