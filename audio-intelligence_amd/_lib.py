@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("conv_Tin", C.c_int), ("conv_Tout", C.c_int), ("conv_stride", C.c_int), ("conv_C", C.c_int),
                 ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
                 ("w_scale", C.c_void_p),
-                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_bias", C.c_void_p), ("row_stats_out", C.c_void_p)]
+                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_bias", C.c_void_p), ("row_stats_out", C.c_void_p),
+                ("a_fp8", C.c_int), ("a_scale", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -52,7 +53,9 @@ class EncoderWeights(C.Structure):
                 ("fc1_w", c_void_pp), ("fc1_b", c_void_pp), ("fc2_w", c_void_pp), ("fc2_b", c_void_pp),
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p),
                 ("qkv_wf", c_void_pp), ("qkv_cs", c_void_pp), ("qkv_bf", c_void_pp),
-                ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp), ("q_prescaled", C.c_int)]
+                ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp), ("q_prescaled", C.c_int),
+                ("qkv_w8", c_void_pp), ("qkv_s8", c_void_pp), ("out_w8", c_void_pp), ("out_s8", c_void_pp),
+                ("fc1_w8", c_void_pp), ("fc1_s8", c_void_pp), ("fc2_w8", c_void_pp), ("fc2_s8", c_void_pp)]
 
 
 class LlmWeights(C.Structure):
@@ -65,7 +68,7 @@ class LlmWeights(C.Structure):
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int),
                 ("qkv_w8", c_void_pp), ("qkv_s", c_void_pp), ("o_w8", c_void_pp), ("o_s", c_void_pp),
                 ("gu_w8", c_void_pp), ("gu_s", c_void_pp), ("down_w8", c_void_pp), ("down_s", c_void_pp),
-                ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p)]
+                ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p), ("fp8_prefill", C.c_int)]
 
 
 class KvCache(C.Structure):
@@ -102,6 +105,7 @@ SIGNATURES = {
     "afhip_rmsnorm": (_I, [_P, _P, _P, _I, _I, _F, _I, _P]),
     "afhip_embed_sum": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "afhip_gather_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "afhip_quant_rows": (_I, [_P, _I, _P, _P, C.c_float, _I, _P, _P, _I, _I, _P]),
     "afhip_ln_stats_finalize": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
     "afhip_row_stats": (_I, [_P, _I, _I, C.c_float, _I, _P, _P]),
     "afhip_rope_kv": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

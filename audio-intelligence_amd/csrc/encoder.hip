@@ -59,6 +59,18 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
     return afhip_gemm(&g, s);
 }
 
+// e4m3 x e4m3 projection: A8 [M,K] bytes + row scales, W8 [N,K] bytes + channel scales -> bf16 C (+bias, act, +residual)
+int gemm8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, const void* res, void* C,
+          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s) {
+    afhip_gemm_args g = {};
+    g.A = A8; g.W = W8; g.bias = bias; g.residual = res; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
+    g.dtype = AFHIP_BF16; g.act = act;
+    g.a_fp8 = 1; g.a_scale = a_scale; g.w_scale = w_scale;
+    return afhip_gemm(&g, s);
+}
+
 }  // namespace
 
 extern "C" size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B) {
@@ -103,6 +115,9 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
     const bool fold = dt == AFHIP_BF16 && w->qkv_wf && w->qkv_cs && w->qkv_bf && w->fc1_wf && w->fc1_cs && w->fc1_bf &&
                       rows >= 512 && d % 256 == 0 && f % 256 == 0 && gemm_pp_available();
     const int P = d / 64;
+    // e4m3-operand mode (BASELINE config 5): explicit LayerNorm fused into the per-row quantisation pass, four fp8 GEMMs per layer
+    const bool f8 = dt == AFHIP_BF16 && w->qkv_w8 && w->qkv_s8 && w->out_w8 && w->out_s8 && w->fc1_w8 && w->fc1_s8 && w->fc2_w8 && w->fc2_s8 &&
+                    d % 256 == 0 && f % 256 == 0;
     for (int l = 0; l < w->n_layers; ++l) {
         afhip_attn_args a = {};
         a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = ws.att;
@@ -113,8 +128,19 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         a.q_head_stride = hd; a.kv_head_stride = hd;
         a.o_head_stride = 0; a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         a.causal = 0; a.q_pos0 = 0; a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt;
-        a.q_prescaled = (fold && w->q_prescaled) ? 1 : 0;
-        if (fold) {
+        a.q_prescaled = (fold && !f8 && w->q_prescaled) ? 1 : 0;
+        if (f8) {
+            float* sc = ws.stats;                           // [rows] row scales of the activation being multiplied
+            if ((rc = afhip_quant_rows(ws.h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = gemm8(ws.ln, sc, w->qkv_w8[l], w->qkv_s8[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, 3 * d, 0, AFHIP_ACT_NONE, s))) return rc;
+            if ((rc = afhip_attention(&a, s))) return rc;
+            if ((rc = afhip_quant_rows(ws.att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
+            if ((rc = afhip_quant_rows(ws.h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
+            if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
+            if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
+        } else if (fold) {
             if (l == 0 && (rc = afhip_row_stats(ws.h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
             if ((rc = gemm(ws.h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
                            ws.stats, w->qkv_cs[l], w->qkv_bf[l], nullptr))) return rc;

@@ -627,6 +627,28 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_gemm: null args");
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_gemm: bad dtype %d", a->dtype);
     AFHIP_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "afhip_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    if (a->a_fp8) {
+        // e4m3 x e4m3 -> bf16 (BASELINE config 5): the persistent ping-pong kernel's F8 form is the one implementation
+        AFHIP_CHECK(a->A && a->W && a->C && a->a_scale && a->w_scale, "afhip_gemm(fp8): null operand / scale");
+        AFHIP_CHECK(a->dtype == AFHIP_BF16, "afhip_gemm(fp8): output / bias / residual dtype must be bf16");
+        AFHIP_CHECK(a->lda >= a->K && a->ldw >= a->K, "afhip_gemm(fp8): lda/ldw < K");
+        AFHIP_CHECK(a->ldc >= (a->act == AFHIP_ACT_SWIGLU ? a->N / 2 : a->N), "afhip_gemm(fp8): ldc too small");
+        AFHIP_CHECK(gemm_pp_eligible(a), "afhip_gemm(fp8): needs N %% 256 == 0, K %% 256 == 0, 16-byte aligned rows (lda, ldw %% 16 == 0), bf16 out, no conv / LN fold / out_f32 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        hipStream_t s8 = (hipStream_t)stream;
+        const bool rec8 = g_prof.on && g_prof.n < g_prof.cap;
+        const int slot8 = g_prof.n;
+        if (rec8) (void)hipEventRecord(g_prof.ev[2 * slot8], s8);
+        const int rc8 = gemm_pp_launch(a, gemm_group_m(), s8);
+        if (rc8 != 0) return rc8;
+        if (rec8) {
+            (void)hipEventRecord(g_prof.ev[2 * slot8 + 1], s8);
+            g_prof.flops[slot8] = 2.0 * (double)a->M * (double)a->N * (double)a->K;
+            g_prof.dtype[slot8] = AFHIP_PROF_FP8 | AFHIP_PROF_PINGPONG;
+            g_prof.n = slot8 + 1;
+        }
+        AFHIP_LAUNCH_CHECK();
+        return 0;
+    }
     const int bk = a->dtype == AFHIP_BF16 ? 64 : 32;
     AFHIP_CHECK(a->K % bk == 0, "afhip_gemm: K=%d must be a multiple of %d", a->K, bk);
     AFHIP_CHECK(a->A && a->W && a->C, "afhip_gemm: null operand");

@@ -66,6 +66,9 @@ struct PPArgs {
     const float* ln_colsum;   // LNFOLD: [N] sum_k W'[n,k]
     const float* ln_bias;     // LNFOLD: [N] f32 bias (b + W beta)
     float* stats_out;         // STATS: [N/64][M][2] partial (sum, sum of squares) of the stored rows
+    const float* a_scale;     // F8: [M] f32 scale of each e4m3 activation row
+    const float* w_scale;     // F8: [N] f32 scale of each e4m3 weight row (output channel)
+    int esz;                  // operand element size in bytes: 2 (bf16) or 1 (e4m3)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -105,14 +108,14 @@ __device__ __forceinline__ void pp_cur_set_tile(const PPArgs& p, PPCur& c, int i
     c.abase = p.A + (long long)m0 * p.lda2;
     c.wbase = p.W + (long long)n0 * p.ldw2;
     const int rows = (p.M - m0) < PP_BM ? (p.M - m0) : PP_BM;
-    c.anrec = (unsigned)(rows - 1) * p.lda2 + (unsigned)p.K * 2u;
-    c.wnrec = (unsigned)(PP_BN - 1) * p.ldw2 + (unsigned)p.K * 2u;
+    c.anrec = (unsigned)(rows - 1) * p.lda2 + (unsigned)(p.K * p.esz);
+    c.wnrec = (unsigned)(PP_BN - 1) * p.ldw2 + (unsigned)(p.K * p.esz);
 }
 
 // next K tile of the stream; past the end of the tile list the cursor stays on the last K tile (the DMAs issued from
 // it land in buffers nobody reads again and only keep the vmcnt bookkeeping uniform)
 __device__ __forceinline__ void pp_cur_advance(const PPArgs& p, PPCur& c, int n_my) {
-    const int kend = p.K * 2 - 128;
+    const int kend = p.K * p.esz - 128;
     if (c.koff < kend) {
         c.koff += 128;
     } else if (c.it + 1 < n_my) {
@@ -148,7 +151,12 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool LNFOLD, bool STATS>
+// F8: both operands are OCP e4m3 bytes (K tile = 128 elements = the same 128-byte LDS rows, so staging, swizzle, phases and
+// vmcnt counts are untouched); a quadrant is 8 x v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 127) -- twice the
+// bf16 MFMA rate -- and the per-row activation scale / per-channel weight scale multiply the f32 accumulator in the epilogue.
+// A lane's 32 K bytes of a step are the two 16-byte chunks the bf16 form reads (q and 4 + q: conflict-free); that K order is not
+// the natural one, but it is the same on both operands, which is all a dot product needs.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool LNFOLD, bool STATS, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int n_my = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nk2 = p.K / (2 * PP_BK);
+    const int nk2 = (p.K * (F8 ? 1 : 2)) / (4 * PP_BK);          // pairs of 128-byte K tiles
 
     // ---- DMA lane constants: instruction u of this wave fills LDS rows (u*8 + wave)*8 + lrow of a half-tile ----
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -225,8 +233,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #if PP_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+        if constexpr (F8) {
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            typedef int v8i_t __attribute__((ext_vector_type(8)));
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const v8i_t w8 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, fbx[j][0]), __builtin_bit_cast(v4i_t, fbx[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v8i_t a8 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, fa[i][0]), __builtin_bit_cast(v4i_t, fa[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[HA][i][HB][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < (F8 ? 0 : 2); ++kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -350,14 +370,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             // gate / up rows are interleaved in 32-row blocks (ParallelLLM.pack): this wave's first 32 columns are the gate,
             // its second 32 the up projection of the same 32 outputs; C is [M, N/2]
             const int ocol = ((n0 + wn * 64) >> 1) + q4 * 8;
+            float sg[8], su[8];
+            if constexpr (F8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sg[e] = p.w_scale[ncol + e]; su[e] = p.w_scale[ncol + 32 + e]; }
+            }
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                    float ra = 1.f;
+                    if constexpr (F8) ra = p.a_scale[m < p.M ? m : p.M - 1];
                     bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)(silu(acc[ha][i][0][e >> 2][e & 3]) * acc[ha][i][1][e >> 2][e & 3]);
+                    for (int e = 0; e < 8; ++e) {
+                        float g = acc[ha][i][0][e >> 2][e & 3], u = acc[ha][i][1][e >> 2][e & 3];
+                        if constexpr (F8) { g *= ra * sg[e]; u *= ra * su[e]; }
+                        o[e] = (bf16)(silu(g) * u);
+                    }
                     if (m < p.M) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ocol) = o;
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb) {
@@ -368,6 +399,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             continue;
         }
         float bv[2][8], cv[2][8];
+        float wsc[2][8], asc[2][4];
+        if constexpr (F8) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.w_scale + ncol + hb * 32), s1 = *reinterpret_cast<const f32x4*>(p.w_scale + ncol + hb * 32 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wsc[hb][e] = s0[e]; wsc[hb][4 + e] = s1[e]; }
+            }
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
+                    m = m < p.M ? m : p.M - 1;
+                    asc[ha][i] = p.a_scale[m];
+                }
+        }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             if constexpr (LNFOLD) {
@@ -429,6 +477,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     for (int e = 0; e < 8; ++e) {
                         float v;
                         if constexpr (LNFOLD) v = fmaf(rstd, fmaf(-mean, cv[hb][e], acc[ha][i][hb][e >> 2][e & 3]), bv[hb][e]);
+                        else if constexpr (F8) v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc[ha][i] * wsc[hb][e], bv[hb][e]);
                         else v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
                         if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
                         if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
@@ -483,13 +532,13 @@ int pp_num_cus() {
     return n;
 }
 
-template <int ACT, bool HB, bool HR, bool LF = false, bool ST = false>
+template <int ACT, bool HB, bool HR, bool LF = false, bool ST = false, bool F8 = false>
 void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
     static unsigned long long attr_done = 0;
     if (afhip_first_use_on_device(&attr_done)) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
+    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
 }
 
 }  // namespace
@@ -500,6 +549,18 @@ bool gemm_pp_available() { return pp_enabled(); }
 // Shapes the ping-pong kernel takes: bf16 in / bf16 out, no implicit conv, whole 256-column tiles,
 // an even number of 64-deep K tiles, 16-byte aligned rows everywhere, operands addressable with 32-bit byte offsets.
 bool gemm_pp_eligible(const afhip_gemm_args* a) {
+    if (a->a_fp8) {
+        // e4m3 operands: this kernel is the only implementation; afhip_gemm reports what is missing when this says no
+        if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0 || !a->a_scale || !a->w_scale) return false;
+        if (a->ln_stats || a->row_stats_out) return false;
+        if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
+        if (a->M < 1 || (a->N % PP_BN) != 0 || (a->K % 256) != 0) return false;
+        if ((a->lda % 16) || (a->ldw % 16) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
+        if (a->bias && ((uintptr_t)a->bias % 16)) return false;
+        if (a->residual && ((a->ldres % 8) || ((uintptr_t)a->residual % 16))) return false;
+        if (((uintptr_t)a->w_scale % 16) || (long long)a->lda * PP_BM >= (1ll << 31) || (long long)a->ldw * PP_BN >= (1ll << 31)) return false;
+        return true;
+    }
     if (!pp_enabled()) return false;
     if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0) return false;
     if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
@@ -518,7 +579,9 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     p.A = (const char*)a->A; p.W = (const char*)a->W;
     p.bias = (const bf16*)a->bias; p.res = (const bf16*)a->residual; p.C = (bf16*)a->C;
     p.M = a->M; p.N = a->N; p.K = a->K;
-    p.lda2 = (unsigned)(a->lda * 2); p.ldw2 = (unsigned)(a->ldw * 2);
+    p.esz = a->a_fp8 ? 1 : 2;
+    p.lda2 = (unsigned)(a->lda * p.esz); p.ldw2 = (unsigned)(a->ldw * p.esz);
+    p.a_scale = a->a_scale; p.w_scale = a->w_scale;
     p.ldc = a->ldc; p.ldres = a->ldres;
     p.act = a->act;
     p.tiles_m = cdiv(a->M, PP_BM); p.tiles_n = a->N / PP_BN; p.group_m = group_m;
@@ -528,6 +591,21 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     const int grid = nwg < ncu ? (int)nwg : ncu;
     const bool hb = a->bias != nullptr, hr = a->residual != nullptr;
     p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_bias = a->ln_bias; p.stats_out = a->row_stats_out;
+    if (a->a_fp8) {
+        if (a->act == AFHIP_ACT_SWIGLU) pp_launch_t<AFHIP_ACT_SWIGLU, false, false, false, false, true>(p, grid, s);
+        else if (a->act == AFHIP_ACT_GELU) {
+            if (hb && hr) pp_launch_t<AFHIP_ACT_GELU, true, true, false, false, true>(p, grid, s);
+            else if (hb) pp_launch_t<AFHIP_ACT_GELU, true, false, false, false, true>(p, grid, s);
+            else if (hr) pp_launch_t<AFHIP_ACT_GELU, false, true, false, false, true>(p, grid, s);
+            else pp_launch_t<AFHIP_ACT_GELU, false, false, false, false, true>(p, grid, s);
+        } else {
+            if (hb && hr) pp_launch_t<AFHIP_ACT_NONE, true, true, false, false, true>(p, grid, s);
+            else if (hb) pp_launch_t<AFHIP_ACT_NONE, true, false, false, false, true>(p, grid, s);
+            else if (hr) pp_launch_t<AFHIP_ACT_NONE, false, true, false, false, true>(p, grid, s);
+            else pp_launch_t<AFHIP_ACT_NONE, false, false, false, false, true>(p, grid, s);
+        }
+        return 0;
+    }
     if (a->ln_stats) {
         if (a->act == AFHIP_ACT_GELU) pp_launch_t<AFHIP_ACT_GELU, false, false, true, false>(p, grid, s);
         else pp_launch_t<AFHIP_ACT_NONE, false, false, true, false>(p, grid, s);

@@ -49,6 +49,18 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
     return ws;
 }
 
+// e4m3 x e4m3 projection of the prefill path (afhip_gemm_args.a_fp8)
+int gemm8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, const void* res, void* C,
+          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s) {
+    afhip_gemm_args g = {};
+    g.A = A8; g.W = W8; g.bias = bias; g.residual = res; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
+    g.dtype = AFHIP_BF16; g.act = act;
+    g.a_fp8 = 1; g.a_scale = a_scale; g.w_scale = w_scale;
+    return afhip_gemm(&g, s);
+}
+
 int gemm_any(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
              int ldc, int ldres, int dtype, int act, int out_f32, hipStream_t s, const void* norm_w = nullptr,
              float norm_eps = 0.f, int a_swiglu = 0, const float* w_scale = nullptr) {
@@ -215,8 +227,17 @@ static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, in
         char* vc = (char*)cache->v + (size_t)l * layer_kv;
         const bool skinny = rows <= 64;       // decode: RMSNorm and SwiGLU are folded into the weight-streaming GEMMs
         const bool f8 = skinny && T == 1 && rows <= 32 && dt == AFHIP_BF16 && w->qkv_w8 != nullptr;   // W8A16 copies of the streamed weights: decode steps only, prefill keeps bf16
+        // prefill on e4m3 operands (BASELINE config 5): the activation of every projection is quantised per row (RMSNorm fused into
+        // that pass); q8 lives in the act2 buffer (rows x inter bytes fit its rows x inter x 2), the row scales in nb
+        const bool p8 = !skinny && dt == AFHIP_BF16 && w->fp8_prefill && w->qkv_w8 && w->o_w8 && w->gu_w8 && w->down_w8 &&
+                        H % 256 == 0 && I % 256 == 0 && (nq * hd) % 256 == 0 && qw % 256 == 0 && I <= 20480;
+        char* q8 = ws.act2;
+        float* sc8 = (float*)ws.nb;
         if (skinny) {
             if ((rc = gemm_any(ws.x, f8 ? w->qkv_w8[l] : w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s, w->ln1_w[l], w->rms_eps, 0, f8 ? w->qkv_s[l] : nullptr))) return rc;
+        } else if (p8) {
+            if ((rc = afhip_quant_rows(ws.x, H, w->ln1_w[l], nullptr, w->rms_eps, 2, q8, sc8, rows, H, s))) return rc;
+            if ((rc = gemm8(q8, sc8, w->qkv_w8[l], w->qkv_s[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, qw, 0, AFHIP_ACT_NONE, s))) return rc;
         } else {
             if ((rc = afhip_rmsnorm(ws.x, w->ln1_w[l], ws.nb, rows, H, w->rms_eps, dt, s))) return rc;
             if ((rc = gemm_any(ws.nb, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, qw, H, H, qw, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
@@ -254,6 +275,15 @@ static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, in
             a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
         }
         if ((rc = afhip_attention(&a, s))) return rc;
+        if (p8) {
+            if ((rc = afhip_quant_rows(ws.att, nq * hd, nullptr, nullptr, 0.f, 0, q8, sc8, rows, nq * hd, s))) return rc;
+            if ((rc = gemm8(q8, sc8, w->o_w8[l], w->o_s[l], nullptr, ws.x, ws.x, rows, H, nq * hd, H, H, AFHIP_ACT_NONE, s))) return rc;
+            if ((rc = afhip_quant_rows(ws.x, H, w->ln2_w[l], nullptr, w->rms_eps, 2, q8, sc8, rows, H, s))) return rc;
+            if ((rc = gemm8(q8, sc8, w->gu_w8[l], w->gu_s[l], nullptr, nullptr, ws.act, rows, 2 * I, H, I, 0, AFHIP_ACT_SWIGLU, s))) return rc;
+            if ((rc = afhip_quant_rows(ws.act, I, nullptr, nullptr, 0.f, 0, q8, sc8, rows, I, s))) return rc;
+            if ((rc = gemm8(q8, sc8, w->down_w8[l], w->down_s[l], nullptr, ws.x, ws.x, rows, H, I, H, H, AFHIP_ACT_NONE, s))) return rc;
+            continue;
+        }
         if ((rc = gemm_any(ws.att, f8 ? w->o_w8[l] : w->o_w[l], nullptr, ws.x, ws.x, rows, H, nq * hd, nq * hd, H, H, dt, AFHIP_ACT_NONE, 0, s, nullptr, 0.f, 0, f8 ? w->o_s[l] : nullptr))) return rc;
         if (skinny) {
             const char* mlp_in = ws.act;

@@ -1,0 +1,122 @@
+// Dynamic per-row e4m3 quantisation of activations for the fp8-operand GEMM (gemm_pp.hip F8 form), with the LayerNorm / RMSNorm
+// that precedes the projection fused in: one workgroup per row, the row stays in registers between the statistics, the amax and
+// the conversion, so the pass costs one bf16 read and one byte write per element.  No reference counterpart (BASELINE config 5).
+#include "common.h"
+
+namespace {
+
+constexpr int QR_THREADS = 256;
+constexpr int QR_MAXCH = 10;          // 16-byte chunks (8 bf16) per thread: D <= 256 * 10 * 8 = 20480
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// MODE 0 plain, 1 LayerNorm, 2 RMSNorm
+template <int MODE>
+__global__ __launch_bounds__(QR_THREADS) void quant_rows_kernel(const bf16* __restrict__ x, long long ld_x, const bf16* __restrict__ w,
+                                                                const bf16* __restrict__ b, float eps, unsigned char* __restrict__ q,
+                                                                float* __restrict__ scale, int D) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const bf16* row = x + (long long)r * ld_x;
+    const int nch = D >> 3;
+    float v[QR_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < QR_MAXCH; ++c) {
+        const int ch = tid + c * QR_THREADS;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(row + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s1 += v[c][e]; s2 = fmaf(v[c][e], v[c][e], s2); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+    if constexpr (MODE == 1) {
+        const float mean = block_sum(s1, sh) / (float)D;
+        float d2 = 0.f;                                   // two-pass variance on the registers: no E[x^2] - mean^2 cancellation
+#pragma unroll
+        for (int c = 0; c < QR_MAXCH; ++c) {
+            const int ch = tid + c * QR_THREADS;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; d2 = fmaf(d, d, d2); }
+            }
+        }
+        const float rstd = rsqrtf(block_sum(d2, sh) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < QR_MAXCH; ++c) {
+            const int ch = tid + c * QR_THREADS;
+            if (ch < nch) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + ch * 8), bb = *reinterpret_cast<const bf16x8*>(b + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = fmaf((v[c][e] - mean) * rstd, (float)g[e], (float)bb[e]);
+            }
+        }
+    } else if constexpr (MODE == 2) {
+        const float rstd = rsqrtf(block_sum(s2, sh) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < QR_MAXCH; ++c) {
+            const int ch = tid + c * QR_THREADS;
+            if (ch < nch) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = (float)g[e] * (float)(bf16)(v[c][e] * rstd);     // modeling_qwen2.py:250-252
+            }
+        }
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < QR_MAXCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[c][e]));
+    am = block_max(am, sh);
+    const float sc = am > 0.f ? am / 448.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (tid == 0) scale[r] = sc;
+    unsigned char* qrow = q + (long long)r * D;
+#pragma unroll
+    for (int c = 0; c < QR_MAXCH; ++c) {
+        const int ch = tid + c * QR_THREADS;
+        if (ch < nch) {
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+            *reinterpret_cast<int2*>(qrow + ch * 8) = make_int2(lo, hi);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
+                                int rows, int D, void* stream) {
+    AFHIP_CHECK(x && q && scale && rows > 0 && D > 0, "afhip_quant_rows: bad args");
+    AFHIP_CHECK(mode >= 0 && mode <= 2, "afhip_quant_rows: mode %d", mode);
+    AFHIP_CHECK((mode == 0) || (w != nullptr && (mode == 2 || b != nullptr)), "afhip_quant_rows: the norm needs its gain (and LayerNorm its bias)");
+    AFHIP_CHECK(D % 8 == 0 && D <= QR_THREADS * QR_MAXCH * 8 && ld_x >= D && ld_x % 8 == 0, "afhip_quant_rows: D=%d must be a multiple of 8, <= %d, rows 16-byte aligned", D, QR_THREADS * QR_MAXCH * 8);
+    AFHIP_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0, "afhip_quant_rows: x must be 16-byte, q 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(rows), block(QR_THREADS);
+    if (mode == 1) hipLaunchKernelGGL(quant_rows_kernel<1>, grid, block, 0, s, (const bf16*)x, (long long)ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, D);
+    else if (mode == 2) hipLaunchKernelGGL(quant_rows_kernel<2>, grid, block, 0, s, (const bf16*)x, (long long)ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, D);
+    else hipLaunchKernelGGL(quant_rows_kernel<0>, grid, block, 0, s, (const bf16*)x, (long long)ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, D);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -103,16 +103,11 @@ class _Backbone(nn.Module):
         self.norm = _Norm(H, bias=False)
 
 
-def _quantize_rows_e4m3(w: torch.Tensor):
-    """[N,K] -> (e4m3 bytes [N,K] as uint8, f32 scale [N]) with w ~= scale[n] * q[n,k]; 448 = e4m3 max."""
-    amax = w.float().abs().amax(dim=1).clamp_min(1e-12)
-    scale = (amax / 448.0).contiguous()
-    q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
-    return q.view(torch.uint8).contiguous(), scale
+from ..utils.quant import quantize_rows_e4m3 as _quantize_rows_e4m3  # noqa: E402
 
 
 def pack_qwen2_weights(backbone: "_Backbone", lm_head_w: torch.Tensor, stream_emb_w: Optional[torch.Tensor], cfg: dict, n_stream: int,
-                       fp8: bool = False, max_positions: Optional[int] = None):
+                       fp8: bool = False, max_positions: Optional[int] = None, fp8_prefill: bool = False):
     """Build `afhip_llm_weights` for a Qwen2 decoder stack held in HF parameter layout: q|k|v fused with biases, gate/up
     interleaved in 32-row blocks (SwiGLU pairs land in one wave's accumulators), RoPE tables exactly as transformers computes
     them (modeling_qwen2.py:91-121), optional e4m3 copies of the weights a decode step streams.  Keeps every tensor alive in
@@ -163,6 +158,7 @@ def pack_qwen2_weights(backbone: "_Backbone", lm_head_w: torch.Tensor, stream_em
             setattr(w, dst_s, C.cast(arrays[dst_s], L.c_void_pp))
         q8, sc = _quantize_rows_e4m3(lm_head_w.detach())
         w.lm_head8, w.lm_head_s = P(q8).data_ptr(), P(sc).data_ptr()
+        w.fp8_prefill = 1 if fp8_prefill else 0
     w.norm_w = P(backbone.norm.weight).data_ptr()
     w.lm_head = P(lm_head_w).data_ptr()
     w.stream_emb = P(stream_emb_w).data_ptr() if stream_emb_w is not None else None
@@ -204,6 +200,7 @@ class ParallelLLM(nn.Module):
         self._ws = None
         self._allowed = {}
         self._fp8_decode = False
+        self._fp8_prefill = False
 
     _quantize_rows_e4m3 = staticmethod(_quantize_rows_e4m3)
 
@@ -214,6 +211,16 @@ class ParallelLLM(nn.Module):
         if on and self.dtype != torch.bfloat16:
             raise L.AfhipError("fp8 decode weights need a bfloat16 model")
         self._fp8_decode = bool(on)
+        if not on:
+            self._fp8_prefill = False
+        self._packed = None
+        return self
+
+    def enable_fp8(self, on: bool = True):
+        """BASELINE config 5 end to end on the LLM side: W8A16 decode (enable_fp8_decode) AND e4m3 x e4m3 MFMA GEMMs for the four
+        projections of every layer in prefill (activations quantised per row, RMSNorm fused into that pass; f32 accumulate)."""
+        self.enable_fp8_decode(on)
+        self._fp8_prefill = bool(on)
         self._packed = None
         return self
 
@@ -287,7 +294,7 @@ class ParallelLLM(nn.Module):
         if self._packed is not None and (max_positions is None or max_positions <= self._packed.max_pos):
             return self._packed
         self._packed = pack_qwen2_weights(self.model, self.lm_head.weight, self.stream_emb.weight, self.cfg, self.num_stream,
-                                          fp8=self._fp8_decode, max_positions=max_positions)
+                                          fp8=self._fp8_decode, max_positions=max_positions, fp8_prefill=self._fp8_prefill)
         return self._packed
 
     def _workspace(self, B, T, max_ctx=0):

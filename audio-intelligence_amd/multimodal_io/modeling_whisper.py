@@ -105,6 +105,16 @@ class AFWhisperEncoder(nn.Module):
         self.layer_norm = _Norm(d)
         self._packed = None
         self._ws = None
+        self._fp8 = False
+
+    def enable_fp8(self, on: bool = True):
+        """BASELINE config 5: run the four projections of every layer on OCP e4m3 operands (weights quantised once per output
+        channel here, activations per row on the device with the LayerNorm fused; f32 accumulate, bf16 stream).  bf16 models only."""
+        if on and self.dtype != torch.bfloat16:
+            raise L.AfhipError("the fp8 encoder path needs a bfloat16 model")
+        self._fp8 = bool(on)
+        self._packed = None
+        return self
 
     # ---------------------------------------------------------------- checkpoints
     @classmethod
@@ -216,6 +226,17 @@ class AFWhisperEncoder(nn.Module):
                     lists[pre + "_cs"].append(P(wf.float().sum(dim=1)))
                     lists[pre + "_bf"].append(P((bt.float() + w32 @ b32) * rs))
         w.q_prescaled = 1 if fold_names else 0
+        if self._fp8 and dt == torch.bfloat16:
+            from ..utils.quant import quantize_rows_e4m3
+            f8_names = []
+            for src in ("qkv", "out", "fc1", "fc2"):
+                lists[src + "_w8"], lists[src + "_s8"] = [], []
+                f8_names += [src + "_w8", src + "_s8"]
+                for t in lists[src + "_w"]:
+                    q8, sc = quantize_rows_e4m3(t)
+                    lists[src + "_w8"].append(P(q8))
+                    lists[src + "_s8"].append(P(sc))
+            fold_names = fold_names + f8_names
         arrays = {}
         for n in names + fold_names:
             arrays[n] = L.ptr_array(lists[n])

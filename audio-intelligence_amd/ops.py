@@ -60,6 +60,40 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def quant_rows(x: torch.Tensor, mode: int = 0, w: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """Per-row e4m3 quantisation of bf16 rows [rows, D] (mode 0), of LayerNorm(x) (1) or RMSNorm(x) (2): (bytes [rows, D] uint8, scale [rows] f32)."""
+    lib = L.lib()
+    _chk(x, "quant_rows.x")
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.bfloat16
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    L.check(lib.afhip_quant_rows(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(b), eps, mode, L.ptr(q), L.ptr(sc), x.shape[0], x.shape[1], L.stream_ptr()))
+    return q, sc
+
+
+def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C (bf16) = epilogue(a_scale[m] * w_scale[n] * (Aq . Wq^T)) on e4m3 bytes aq [M,K], wq [N,K] (uint8 views)."""
+    lib = L.lib()
+    _chk(aq, "gemm_fp8.aq")
+    M, K = aq.shape
+    N = wq.shape[0]
+    n_out = N // 2 if act == L.ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.bfloat16, device=aq.device)
+    args = L.GemmArgs()
+    args.A, args.W, args.C = aq.data_ptr(), wq.data_ptr(), out.data_ptr()
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.residual = residual.data_ptr() if residual is not None else None
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldw, args.ldc = aq.stride(0), wq.stride(0), out.stride(0)
+    args.ldres = residual.stride(0) if residual is not None else 0
+    args.dtype, args.act = L.BF16, act
+    args.a_fp8, args.a_scale, args.w_scale = 1, a_scale.data_ptr(), w_scale.data_ptr()
+    L.check(lib.afhip_gemm(C.byref(args), L.stream_ptr()))
+    return out
+
+
 def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """[rows, D] -> [rows, 2] f32 (mean, rsqrt(var + eps)): the LayerNorm statistics of the GEMM-folded form."""
     lib = L.lib()

@@ -97,6 +97,13 @@ typedef struct {
     const float* ln_colsum;
     const float* ln_bias;
     float* row_stats_out;
+    /* afhip_gemm only: e4m3 x e4m3 operands (BASELINE config 5 "fp8 MFMA GEMMs"; no reference counterpart).  a_fp8 != 0: A is OCP
+     * e4m3 bytes [M, lda] with one f32 scale per row (a_scale [M], from afhip_quant_rows), W is e4m3 bytes [N, ldw] with one f32
+     * scale per output channel (w_scale [N]); C = epilogue(a_scale[m] * w_scale[n] * (Aq . Wq^T)) in bf16 (`dtype` = AFHIP_BF16
+     * names the type of C / bias / residual).  f32 accumulation on the block-scaled MFMA with unit block scales (twice the bf16
+     * MFMA rate).  Needs N % 256 == 0, K % 256 == 0, lda / ldw % 16 == 0; bias / GELU / residual / SWIGLU epilogues as for bf16. */
+    int a_fp8;
+    const float* a_scale;
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
@@ -106,6 +113,7 @@ int afhip_gemm(const afhip_gemm_args* args, void* stream);
  * Launches served by the persistent ping-pong kernel (gemm_pp.hip) are recorded as `dtype | AFHIP_PROF_PINGPONG`, so the
  * roofline leg can quote that kernel alone (its rocprofv3 rows) and the remaining launches separately. */
 #define AFHIP_PROF_PINGPONG 0x100
+#define AFHIP_PROF_FP8 0x200       /* e4m3-operand launches are recorded as AFHIP_PROF_FP8 | AFHIP_PROF_PINGPONG */
 int afhip_prof_enable(int max_launches);
 int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops);
 
@@ -129,6 +137,13 @@ int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float 
 /* LayerNorm statistics for the folded form above.  finalize: partials [P][rows][2] (sum, sum of squares over D/P columns
  * each) -> stats [rows][2] = (mean, rsqrt(var + eps)), var = E[x^2] - mean^2 in f32.  row_stats: the same from the rows
  * themselves (first layer, whose input comes from the conv stem). */
+/* Dynamic per-row e4m3 quantisation of activations for the fp8-operand GEMM, with the normalisation in front of it fused:
+ *   mode 0: y = x              mode 1: y = LayerNorm(x; w, b, eps) (modeling_whisper.py:490,501)
+ *   mode 2: y = RMSNorm(x; w, eps) (modeling_qwen2.py:238-252; x*rstd rounded to bf16 before the gain, like the reference)
+ * q[r, :] = e4m3(y[r, :] / s[r]), s[r] = max|y[r, :]| / 448 (1 for an all-zero row).  x [rows, ld_x] bf16, q [rows, D] bytes,
+ * scale [rows] f32.  D % 8 == 0, D <= 20480. */
+int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
+                     int rows, int D, void* stream);
 int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream);
 int afhip_row_stats(const void* x, int rows, int D, float eps, int dtype, float* stats, void* stream);
 /* Row gather of the AF3 / Qwen2-Audio placeholder merge: replaces the three index_put / masked assignments of
@@ -228,6 +243,14 @@ typedef struct {
     const void* const* qkv_wf; const float* const* qkv_cs; const float* const* qkv_bf;
     const void* const* fc1_wf; const float* const* fc1_cs; const float* const* fc1_bf;
     int q_prescaled;  /* != 0: the q rows of qkv_wf / qkv_cs / qkv_bf also carry head_dim^-0.5 * log2(e) (softmax scale in exp2 units) */
+    /* optional, bf16 models only (all eight or none): OCP e4m3 copies of the four projection weights of every layer + one f32
+     * scale per output channel.  When present the layer runs its GEMMs on e4m3 operands (BASELINE config 5): each projection's
+     * input is quantised per row by afhip_quant_rows (the two LayerNorms fused into that pass, no LayerNorm fold), f32 accumulate,
+     * bf16 residual stream / attention unchanged.  No reference counterpart: tolerance = error vs the bf16 path (tests). */
+    const void* const* qkv_w8; const float* const* qkv_s8;
+    const void* const* out_w8; const float* const* out_s8;
+    const void* const* fc1_w8; const float* const* fc1_s8;
+    const void* const* fc2_w8; const float* const* fc2_s8;
 } afhip_encoder_weights;
 size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 /* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);
@@ -264,6 +287,9 @@ typedef struct {
     const void* const* gu_w8; const float* const* gu_s;
     const void* const* down_w8; const float* const* down_s;
     const void* lm_head8; const float* lm_head_s;
+    /* != 0 (needs the e4m3 copies above): prefill (T > 1, more than 64 rows) also runs its four projections per layer on e4m3
+     * operands -- activations quantised per row by afhip_quant_rows with the RMSNorm fused -- instead of bf16 */
+    int fp8_prefill;
 } afhip_llm_weights;
 
 typedef struct {

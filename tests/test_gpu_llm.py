@@ -177,32 +177,6 @@ def test_checkpoint_reload_rebuilds_packed_weights(stack_f32, tmp_path):
         assert torch.equal(got, want), f"{dtype}: stale packed weights survived load_checkpoint"
 
 
-def test_fp8_decode_weights_track_bf16():
-    """W8A16 decode (config 5): no bit-exact contract; the fp8-weight decode must stay close to the bf16 one -- the first
-    greedy tokens (large top-2 gaps) agree and the decode-step logits correlate > 0.99."""
-    _need_gpu()
-    model, pre = H.build_tiny_ualm(torch.bfloat16, DEV)
-    kw = _to_dev(_sample(1000, pre), torch.bfloat16)
-    kw.pop("loss_masks")
-    ref = model.inference_segment(CFG, cache=None, enforce_modality="text", **kw)[0][0][0][:, 0].cpu().tolist()
-    ids = torch.cat([kw["seqs"], model.assistant_token], dim=1)
-    emb = model._embed(ids, kw)
-    _, c0 = model._step(input_embeds=emb)
-    tok = model.text_token.clone()
-    lg_bf16, _ = model._step(input_ids=tok, past_key_values=c0)
-    model.enable_fp8_decode(True)
-    got = model.inference_segment(CFG, cache=None, enforce_modality="text", **kw)[0][0][0][:, 0].cpu().tolist()
-    _, c1 = model._step(input_embeds=emb)
-    lg_fp8, _ = model._step(input_ids=tok, past_key_values=c1)
-    a, b = lg_bf16[0, 0, 0].float().cpu(), lg_fp8[0, 0, 0].float().cpu()
-    corr = float(torch.corrcoef(torch.stack([a, b]))[0, 1])
-    n = 0
-    while n < min(len(got), len(ref)) and got[n] == ref[n]:
-        n += 1
-    print(f"fp8 decode: logits corr {corr:.4f}, greedy prefix match {n}/{len(ref)}")
-    assert corr > 0.99 and n >= 1
-
-
 def test_driver_run_inference_matches_golden_and_isolates_errors(stack_f32, tmp_path):
     """SURVEY 8f rows 1 + 3: checkpoint -> fresh model -> run_inference (scripts/inference.py:136-153, 270-304) reproduces the
     reference's greedy token ids; a broken sample is reported and does not stop the shard."""
