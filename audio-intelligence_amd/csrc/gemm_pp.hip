@@ -204,6 +204,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef int v8i_t __attribute__((ext_vector_type(8)));
+    const int unit_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte: block scales off
+    v8i_t fa8[4], fb0_8[2], fb1_8[2];       // F8: a lane's 32 K bytes of a step as ONE 8-dword MFMA operand (loaded as two 16-B halves)
 
     // ---- prologue: A0 B0 B1 A1 of stream tile 0 (stage 0), A0 B0 of stream tile 1 (stage 1) ----
     PPCur c1, c2;
@@ -234,16 +238,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         __builtin_amdgcn_s_setprio(1);
 #endif
         if constexpr (F8) {
-            typedef int v4i_t __attribute__((ext_vector_type(4)));
-            typedef int v8i_t __attribute__((ext_vector_type(8)));
+            v8i_t (&fb8)[2] = (HB == 0) ? fb0_8 : fb1_8;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const v8i_t w8 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, fbx[j][0]), __builtin_bit_cast(v4i_t, fbx[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-                    const v8i_t a8 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, fa[i][0]), __builtin_bit_cast(v4i_t, fa[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[HA][i][HB][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                }
+                for (int j = 0; j < 2; ++j)
+                    // inline asm with the accumulator TIED (dst == srcC): left to the builtin, hipcc allocates a fresh destination per
+                    // MFMA of this VGPR-form instruction and spills ~150 registers in the K loop (3x slower than the bf16 form).
+                    // Hazards: operands come from ds_read (the compiler waits on lgkmcnt for asm inputs); the accumulators are
+                    // next read by VALU code a barrier and the whole tile-coordinate computation later.
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[HA][i][HB][j]) : "v"(fb8[j]), "v"(fa8[i]), "v"(unit_scale));
         }
 #pragma unroll
         for (int kk = 0; kk < (F8 ? 0 : 2); ++kk) {
@@ -267,6 +272,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     // fragment reads in the order the MFMAs consume them (K half 0 of every tile, then K half 1): with per-fragment lgkmcnt waits
     // the first MFMAs start while the second half is still in flight
     auto read_a = [&](const char* half) {
+        if constexpr (F8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i_t lo = *reinterpret_cast<const v4i_t*>(half + aoff0 + i * 2048), hi = *reinterpret_cast<const v4i_t*>(half + aoff1 + i * 2048);
+                fa8[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            return;
+        }
 #if PP_VARIANT & 4
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -281,6 +294,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #endif
     };
     auto read_b = [&](const char* half, bf16x8 (&fbx)[2][2]) {
+        if constexpr (F8) {
+            v8i_t (&fb8)[2] = (&fbx == &fb0) ? fb0_8 : fb1_8;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const v4i_t lo = *reinterpret_cast<const v4i_t*>(half + boff0 + j * 2048), hi = *reinterpret_cast<const v4i_t*>(half + boff1 + j * 2048);
+                fb8[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            return;
+        }
 #if PP_VARIANT & 4
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             continue;
         }
         float bv[2][8], cv[2][8];
-        float wsc[2][8], asc[2][4];
+        float wsc[2][8];
         if constexpr (F8) {
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -407,14 +429,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { wsc[hb][e] = s0[e]; wsc[hb][4 + e] = s1[e]; }
             }
-#pragma unroll
-            for (int ha = 0; ha < 2; ++ha)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
-                    m = m < p.M ? m : p.M - 1;
-                    asc[ha][i] = p.a_scale[m];
-                }
         }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         // residual: all 16 loads of the lane are issued before the first use (one exposed latency per tile instead of
         // eight); rows past M are clamped for the load and masked at the store
         bf16x8 r8[2][4][2];
-        if constexpr (HAS_RES) {
+        if constexpr (HAS_RES && !F8) {
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -467,8 +481,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
                 const bool ok = m < p.M;
-                float mean = 0.f, rstd = 1.f;
+                if constexpr (HAS_RES && F8) {
+                    // F8 keeps 16 scale registers live: the residual rows are loaded per row group instead of all 16 up front
+                    const int mr = ok ? m : p.M - 1;
+                    r8[ha][i][0] = *reinterpret_cast<const bf16x8*>(p.res + (long long)mr * p.ldres + ncol);
+                    r8[ha][i][1] = *reinterpret_cast<const bf16x8*>(p.res + (long long)mr * p.ldres + ncol + 32);
+                }
+                float mean = 0.f, rstd = 1.f, asc = 1.f;
                 if constexpr (LNFOLD) { mean = st2[ha][i][0]; rstd = st2[ha][i][1]; }
+                if constexpr (F8) asc = p.a_scale[ok ? m : p.M - 1];
                 rs[ha][i] = 0.f; rss[ha][i] = 0.f;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     for (int e = 0; e < 8; ++e) {
                         float v;
                         if constexpr (LNFOLD) v = fmaf(rstd, fmaf(-mean, cv[hb][e], acc[ha][i][hb][e >> 2][e & 3]), bv[hb][e]);
-                        else if constexpr (F8) v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc[ha][i] * wsc[hb][e], bv[hb][e]);
+                        else if constexpr (F8) v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc * wsc[hb][e], bv[hb][e]);
                         else v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
                         if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
                         if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
