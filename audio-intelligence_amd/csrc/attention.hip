@@ -449,10 +449,6 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 
 }  // namespace
 
-// ping-pong kernel for the encoder shape (attention_pp.hip)
-bool attn_pp_eligible(const afhip_attn_args* a);
-int attn_pp_launch(const afhip_attn_args* a, hipStream_t s);
-
 extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_attention: null args");
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_attention: bad dtype %d", a->dtype);
@@ -470,12 +466,6 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     AFHIP_CHECK(a->ld_o >= a->hd, "afhip_attention: ld_o too small");
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
 
-    if (attn_pp_eligible(a)) {
-        const int rc = attn_pp_launch(a, (hipStream_t)stream);
-        if (rc != 0) return rc;
-        AFHIP_LAUNCH_CHECK();
-        return 0;
-    }
     AttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;
     p.key_len = a->key_len;

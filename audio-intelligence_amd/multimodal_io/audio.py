@@ -60,6 +60,12 @@ class ContinuousAudioIO(AbsIO):
     def preprocess(self, data: Tuple[np.ndarray, int]):
         """audio.py:1013-1101: (wav, sr) -> (zeros[after,1] int32, (after, mel[3000,128] f32), zeros[after,1])."""
         wav, fs = data
+        import torch.utils.data as _tud
+        if _tud.get_worker_info() is not None:
+            # the reference's worker copy computes the mel on the CPU; here the log-mel IS a HIP kernel, and a forked DataLoader worker
+            # cannot re-initialise the HIP runtime (a spawned one would open one GPU context per worker)
+            raise RuntimeError("ContinuousAudioIO.preprocess runs the log-mel kernel on the GPU: call it in the main process "
+                               "(DataLoader num_workers=0), or feed raw waveforms to encode_wav_batch")
         if fs != self.sample_rate:
             raise ValueError(f"sampling rate {fs} != {self.sample_rate}: resample first (the reference calls librosa.resample, audio.py:1034)")
         if len(wav.shape) > 1:

@@ -188,8 +188,7 @@ typedef struct {
     void* partial_ws;          /* f32 scratch, ceil(Tk/key_split) * B * n_q * 32 * (hd + 2) * 4 bytes */
     size_t partial_ws_bytes;
     int q_prescaled;           /* != 0: q already carries scale * log2(e) (folded into the q projection by the caller, one rounding);
-                                * `scale` is ignored and exp2 is taken of the raw scores.  Lets the software-pipelined kernel
-                                * (attention_pp.hip) run without its own second rounding of q. */
+                                * `scale` is ignored and exp2 is taken of the raw scores (one VALU op per score less). */
     /* Decode only (key_split > 0): rotate-half RoPE and the KV-cache append folded into this launch, so a decode step needs no
      * afhip_rope_kv pass.  new_k != NULL switches it on: q rows are rotated as they are loaded (cos/sin rows of the token's
      * position); the workgroup whose key range holds position Tk-1 reads the token's un-rotated k and its v from

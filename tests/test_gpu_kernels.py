@@ -498,32 +498,28 @@ def test_gemm_pingpong_persistent_path():
     assert torch.equal(c[:256], wif.T.contiguous()) and float(c[256:].abs().max()) == 0.0
 
 
-def test_attention_software_pipelined_opt_in():
-    """attention_pp.hip (AFHIP_ATTN_PP=1): encoder shape, ragged key lengths, a spike that forces the lagged-max rescale."""
-    import os
+def test_attention_encoder_shape_ragged_and_spike():
+    """Encoder attention shape (hd 64, T up to 1500) in bf16: ragged key lengths (a clip with ONE valid key) and a spike that moves
+    the running max mid-sequence (the rescale branch), against fp32 softmax."""
     from audio_intelligence_amd import ops
-    os.environ["AFHIP_ATTN_PP"] = "1"
-    try:
-        for (B, T, H, lens, spike) in [(2, 1500, 4, None, False), (3, 700, 2, [700, 333, 65], False), (2, 1500, 2, [1500, 1], True)]:
-            d = H * 64
-            g = torch.Generator().manual_seed(7)
-            qkv = torch.randn(B, T, 3 * d, generator=g)
-            if spike:
-                qkv[:, T // 2, d:2 * d] *= 6.0
-            qd = qkv.to(torch.bfloat16).to(_dev())
-            qf = qd.float().cpu()
-            kl = torch.tensor(lens, dtype=torch.int32, device=_dev()) if lens else None
-            out = ops.attention_packed(qd, H, key_len=kl).float().cpu()
-            q, k, v = [x.reshape(B, T, H, 64).permute(0, 2, 1, 3) for x in qf.split(d, dim=2)]
-            s = q @ k.transpose(-1, -2) / 8.0
-            if lens:
-                mask = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
-                s = s.masked_fill(mask[:, None, None, :], float("-inf"))
-            ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, d)
-            assert not torch.isnan(out).any()
-            assert float((out - ref).abs().max()) <= (0.06 if spike else 0.02), f"attention_pp B={B} T={T} lens={lens}"
-    finally:
-        os.environ.pop("AFHIP_ATTN_PP", None)
+    for (B, T, H, lens, spike) in [(2, 1500, 4, None, False), (3, 700, 2, [700, 333, 65], False), (2, 1500, 2, [1500, 1], True)]:
+        d = H * 64
+        g = torch.Generator().manual_seed(7)
+        qkv = torch.randn(B, T, 3 * d, generator=g)
+        if spike:
+            qkv[:, T // 2, d:2 * d] *= 6.0
+        qd = qkv.to(torch.bfloat16).to(_dev())
+        qf = qd.float().cpu()
+        kl = torch.tensor(lens, dtype=torch.int32, device=_dev()) if lens else None
+        out = ops.attention_packed(qd, H, key_len=kl).float().cpu()
+        q, k, v = [x.reshape(B, T, H, 64).permute(0, 2, 1, 3) for x in qf.split(d, dim=2)]
+        s = q @ k.transpose(-1, -2) / 8.0
+        if lens:
+            mask = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
+            s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+        ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, d)
+        assert not torch.isnan(out).any()
+        assert float((out - ref).abs().max()) <= (0.06 if spike else 0.02), f"attention B={B} T={T} lens={lens}"
 
 
 def test_gemm_layernorm_folded_forms():
@@ -606,3 +602,21 @@ def test_attention_decode_fused_rope_append_is_bit_identical(dt, nq, nkv, hd, tk
     out_d = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw, in_launch_merge=True)
     out_e = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw)
     assert torch.equal(out_d, out_e)
+
+
+def test_torch_library_ops_dispatch_to_the_hip_library():
+    """torch.ops.afhip.* (torch_ops.py) run the same C-ABI kernels as ops.py: identical bits."""
+    import audio_intelligence_amd.torch_ops  # noqa: F401
+    from audio_intelligence_amd import ops, _lib as L
+    a = _rand(300, 256, seed=41).to(torch.bfloat16).to(_dev())
+    w = (_rand(512, 256, seed=42) * 0.05).to(torch.bfloat16).to(_dev())
+    b = _rand(512, seed=43).to(torch.bfloat16).to(_dev())
+    assert torch.equal(torch.ops.afhip.gemm(a, w, b, L.ACT_GELU, None), ops.gemm(a, w, bias=b, act=L.ACT_GELU))
+    g = (1 + 0.1 * _rand(256, seed=44)).to(torch.bfloat16).to(_dev())
+    assert torch.equal(torch.ops.afhip.rmsnorm(a, g, 1e-6), ops.rmsnorm(a, g, 1e-6))
+    q1, s1 = torch.ops.afhip.quant_rows(a, 2, g, None, 1e-6)
+    q2, s2 = ops.quant_rows(a, 2, g, None, 1e-6)
+    assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    wav = (_rand(2, 480000, seed=45) * 0.1).to(_dev())
+    mel = torch.ops.afhip.log_mel(wav, True, torch.float32)
+    assert tuple(mel.shape) == (2, 3000, 128)

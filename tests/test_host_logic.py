@@ -232,3 +232,31 @@ def test_af3_prepare_inputs_for_generation_known_answers():
         assert r["input_ids"].tolist() == e["input_ids"], c["name"]
         assert (None if r["position_ids"] is None else r["position_ids"].tolist()) == e["position_ids"], c["name"]
         assert (None if r["attention_mask"] is None else r["attention_mask"].tolist()) == e["attention_mask"], c["name"]
+
+
+def test_torch_library_ops_registered_with_meta_kernels():
+    """The stateless C-ABI entry points are also `torch.ops.afhip.*` custom ops (BASELINE north star / SURVEY 8b): registered with
+    schemas and meta kernels, so shapes propagate under FakeTensorMode with no GPU; there is no CPU kernel (no fallback)."""
+    import torch
+    import audio_intelligence_amd.torch_ops as T
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert T.OP_NAMES == sorted(["gemm", "layernorm", "rmsnorm", "embed_sum", "attention_packed", "log_mel", "quant_rows", "gemm_fp8"])
+    for n in T.OP_NAMES:
+        assert hasattr(torch.ops.afhip, n)
+    with FakeTensorMode():
+        a = torch.empty((300, 1280), dtype=torch.bfloat16, device="cuda")
+        w = torch.empty((5120, 1280), dtype=torch.bfloat16, device="cuda")
+        y = torch.ops.afhip.gemm(a, w, None, 1, None)
+        assert tuple(y.shape) == (300, 5120) and y.dtype == torch.bfloat16
+        g = torch.ops.afhip.gemm(a, w, None, 2, None)
+        assert tuple(g.shape) == (300, 2560)
+        q, s = torch.ops.afhip.quant_rows(a, 1, w[0], w[0], 1e-5)
+        assert q.dtype == torch.uint8 and tuple(s.shape) == (300,)
+        mel = torch.ops.afhip.log_mel(torch.empty((4, 480000), device="cuda"), True, torch.bfloat16)
+        assert tuple(mel.shape) == (4, 3000, 128) and mel.dtype == torch.bfloat16
+        att = torch.ops.afhip.attention_packed(torch.empty((2, 1500, 3840), dtype=torch.bfloat16, device="cuda"), 20, None, False)
+        assert tuple(att.shape) == (2, 1500, 1280)
+    # real CPU tensors: no kernel for that backend -> an error, never a silent fallback
+    import pytest
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.afhip.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-6)
