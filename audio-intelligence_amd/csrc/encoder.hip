@@ -7,6 +7,7 @@
 //          (bf16 throughput mode: both LNs folded into the GEMMs around them, see `fold` below)
 //   tail : AvgPool1d(2,2) + LayerNorm fused
 #include "common.h"
+#include <stdlib.h>
 
 bool gemm_pp_available();   // gemm_pp.hip
 
@@ -138,8 +139,17 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
             if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
             if ((rc = afhip_quant_rows(ws.h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
             if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
-            if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
-            if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
+            // fc2 stays bf16: its input is the [rows, ffn] GELU output, and a per-row quantisation pass over it (492 MB read +
+            // 246 MB written, 109 us at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us); the other three inputs are
+            // d-wide (40-45 us per pass, two of them with the LayerNorm they replace fused in).  AFHIP_FP8_FC2=1 switches it on.
+            static int fc2_f8 = -1;
+            if (fc2_f8 < 0) { const char* e = getenv("AFHIP_FP8_FC2"); fc2_f8 = (e && e[0] == '1') ? 1 : 0; }
+            if (fc2_f8) {
+                if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
+                if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
+            } else {
+                if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            }
         } else if (fold) {
             if (l == 0 && (rc = afhip_row_stats(ws.h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
             if ((rc = gemm(ws.h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,

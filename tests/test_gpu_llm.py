@@ -200,6 +200,12 @@ def test_driver_run_inference_matches_golden_and_isolates_errors(stack_f32, tmp_
     res = inf.run_inference(fresh, pre2, samples, CFG, device=DEV, dtype=torch.float32, enforce_modality="text",
                             on_result=lambda i, k, r: seen.append(k))
     assert seen == ["clip0", "broken", "clip1"]
+    # the same shard with batching: clip0 | broken | clip1, clip2 (one B = 2 call): identical ids, error still isolated
+    samples_b = samples + [(("audio_to_caption", "synthetic", "clip2"), {"audio": (fc.make_wav(1002, 160000)[None], 16000), "text": [["user", "text", prompt]]})]
+    res_b = inf.run_inference(fresh, pre2, samples_b, CFG, device=DEV, dtype=torch.float32, enforce_modality="text", batch_size=4)
+    assert "error" in res_b["broken"] and list(res_b.keys()) == ["clip0", "broken", "clip1", "clip2"]
+    for i in range(3):
+        assert [row[0] for row in res_b[f"clip{i}"][0][2]] == gold[i], f"batched clip {i}"
     assert "error" in res["broken"]                                   # 8 kHz audio: the caller must resample
     for i in range(2):
         role, modality, ids = res[f"clip{i}"][0]
