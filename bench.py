@@ -394,13 +394,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    # rehearsal switch (one-GPU box): AFHIP_BENCH_REHEARSAL=1 runs N ranks on ONE device over gloo, to exercise the multi-process
+    # code path (rendezvous, barriers, max-over-ranks, the long-audio gather) where no second GPU exists.  Never a measurement.
+    rehearsal = os.environ.get("AFHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
     lib = L.lib()
 
     B, dtype = args.batch, torch.bfloat16
