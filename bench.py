@@ -281,8 +281,8 @@ def decode_leg(device, model, n_vocab, fe, B, n_steps, warm, config_name):
     hid16, c16 = model._forward_hidden(emb, model.new_cache(B, T + 16))
     torch.cuda.synchronize()
     res["prefill_llm_only_s"] = time.perf_counter() - t0
-    d = (hid8.float() - hid16.float()).abs()
-    res["fp8_weights"]["prefill_hidden_vs_bf16_mean_abs"] = float(d.mean())
+    # (no accuracy figure here: 28 randomly initialised layers are chaotic under ANY perturbation -- the reference's own bf16 path
+    #  loses 0.28 mean |err| after two of them, tests/golden/golden_7b.json; fp8 accuracy is budgeted in tests/test_gpu_fp8.py)
     del hid8, hid16, c8, c16, emb
     return res
 
@@ -335,7 +335,7 @@ def long_audio_workload(args, device, dist, rank, world, enc, fe):
         shard = gathers[0]["gather_bytes"]
         ms = sum(gather_ms) / len(gather_ms)
         sent = (world - 1) * shard
-        res["collective"] = {"op": "all_gather_into_tensor (RCCL over xGMI)", "shard_bytes": shard, "ms": ms, "bytes_sent_per_rank": sent,
+        res["collective"] = {"op": "all_gather_into_tensor (RCCL over xGMI)" if os.environ.get("AFHIP_BENCH_REHEARSAL") != "1" else "all_gather_into_tensor (gloo REHEARSAL on one GPU: not a measurement)", "shard_bytes": shard, "ms": ms, "bytes_sent_per_rank": sent,
                              "GBps_per_rank": sent / (ms * 1e-3) / 1e9, "xgmi_peak_GBps_per_rank": 7 * 153.0,
                              "frac_of_xgmi": sent / (ms * 1e-3) / 1e9 / (7 * 153.0)}
     else:
