@@ -103,6 +103,100 @@ __global__ __launch_bounds__(QR_THREADS) void quant_rows_kernel(const bf16* __re
     }
 }
 
+// Rows of up to 64 * 8 * QW_MAXCH elements (the encoder's 1280, the LLM's 3584): ONE WAVE per row, four rows per workgroup -- no
+// LDS, no barriers, every reduction a wave reduction; the workgroup-per-row form above leaves 96 of its 256 lanes idle at D = 1280
+// and pays six barriers per row (measured 1.25 TB/s; this form streams).
+constexpr int QW_MAXCH = 8;
+template <int MODE, int NCH>
+__global__ __launch_bounds__(QR_THREADS) void quant_rows_wave_kernel(const bf16* __restrict__ x, long long ld_x, const bf16* __restrict__ w,
+                                                                     const bf16* __restrict__ b, float eps, unsigned char* __restrict__ q,
+                                                                     float* __restrict__ scale, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (QR_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16* row = x + (long long)r * ld_x;
+    const int nch = D >> 3;
+    float v[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(row + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s1 += v[c][e]; s2 = fmaf(v[c][e], v[c][e], s2); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+    if constexpr (MODE == 1) {
+        const float mean = wave_sum(s1) / (float)D;
+        float d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (lane + c * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; d2 = fmaf(d, d, d2); }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(d2) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + ch * 8), bb = *reinterpret_cast<const bf16x8*>(b + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = fmaf((v[c][e] - mean) * rstd, (float)g[e], (float)bb[e]);
+            }
+        }
+    } else if constexpr (MODE == 2) {
+        const float rstd = rsqrtf(wave_sum(s2) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = (float)g[e] * (float)(bf16)(v[c][e] * rstd);     // modeling_qwen2.py:250-252
+            }
+        }
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[c][e]));
+    am = wave_max(am);
+    const float sc = am > 0.f ? am / 448.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[r] = sc;
+    unsigned char* qrow = q + (long long)r * D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+            *reinterpret_cast<int2*>(qrow + ch * 8) = make_int2(lo, hi);
+        }
+    }
+}
+
+template <int MODE>
+void launch_wave_form(const bf16* x, long long ld_x, const bf16* w, const bf16* b, float eps, unsigned char* q, float* scale, int rows, int D,
+                      hipStream_t s) {
+    const dim3 grid((rows + QR_THREADS / 64 - 1) / (QR_THREADS / 64)), block(QR_THREADS);
+    const int nch = ((D >> 3) + 63) / 64;
+    if (nch <= 2) hipLaunchKernelGGL((quant_rows_wave_kernel<MODE, 2>), grid, block, 0, s, x, ld_x, w, b, eps, q, scale, rows, D);
+    else if (nch <= 3) hipLaunchKernelGGL((quant_rows_wave_kernel<MODE, 3>), grid, block, 0, s, x, ld_x, w, b, eps, q, scale, rows, D);
+    else if (nch <= 5) hipLaunchKernelGGL((quant_rows_wave_kernel<MODE, 5>), grid, block, 0, s, x, ld_x, w, b, eps, q, scale, rows, D);
+    else hipLaunchKernelGGL((quant_rows_wave_kernel<MODE, QW_MAXCH>), grid, block, 0, s, x, ld_x, w, b, eps, q, scale, rows, D);
+}
+
 }  // namespace
 
 extern "C" int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
@@ -113,6 +207,13 @@ extern "C" int afhip_quant_rows(const void* x, int ld_x, const void* w, const vo
     AFHIP_CHECK(D % 8 == 0 && D <= QR_THREADS * QR_MAXCH * 8 && ld_x >= D && ld_x % 8 == 0, "afhip_quant_rows: D=%d must be a multiple of 8, <= %d, rows 16-byte aligned", D, QR_THREADS * QR_MAXCH * 8);
     AFHIP_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0, "afhip_quant_rows: x must be 16-byte, q 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (D <= 64 * 8 * QW_MAXCH) {
+        if (mode == 1) launch_wave_form<1>((const bf16*)x, ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, rows, D, s);
+        else if (mode == 2) launch_wave_form<2>((const bf16*)x, ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, rows, D, s);
+        else launch_wave_form<0>((const bf16*)x, ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, rows, D, s);
+        AFHIP_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid(rows), block(QR_THREADS);
     if (mode == 1) hipLaunchKernelGGL(quant_rows_kernel<1>, grid, block, 0, s, (const bf16*)x, (long long)ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, D);
     else if (mode == 2) hipLaunchKernelGGL(quant_rows_kernel<2>, grid, block, 0, s, (const bf16*)x, (long long)ld_x, (const bf16*)w, (const bf16*)b, eps, (unsigned char*)q, scale, D);

@@ -502,7 +502,7 @@ def main():
     d8 = (out8.float() - ref_out.float()).abs()
     enc8 = {"encoder_ms": enc8_ms, "encoder_audio_s_per_s": B * 30.0 / (enc8_ms * 1e-3), "speedup_vs_bf16": enc_ms / enc8_ms,
             "vs_bf16_output_max_abs": float(d8.max()), "vs_bf16_output_mean_abs": float(d8.mean()),
-            "what": "e4m3 x e4m3 MFMA GEMMs for qkv / out / fc1 / fc2 (per-row activation scales, per-channel weight scales, f32 accumulate), bf16 stream and attention"}
+            "what": "e4m3 x e4m3 MFMA GEMMs for qkv / out / fc1 (per-row activation scales from a fused LayerNorm + quantise pass, per-channel weight scales, f32 accumulate); fc2, the residual stream and attention stay bf16"}
     enc.enable_fp8(False)
     del ref_out, out8, d8
 

@@ -31,7 +31,7 @@ def test_quant_rows_matches_torch(mode):
     _need_gpu()
     from audio_intelligence_amd import ops
     g = torch.Generator().manual_seed(mode)
-    for rows, D in ((37, 1280), (5, 18944), (3, 256)):
+    for rows, D in ((37, 1280), (5, 18944), (3, 256), (9, 3584), (6, 4096), (2, 4104)):
         x = (torch.randn(rows, D, generator=g) * 1.7 + 0.2).to(torch.bfloat16)
         x[0, 5] = 30.0                                                    # an outlier channel sets that row's scale
         w = (1 + 0.1 * torch.randn(D, generator=g)).to(torch.bfloat16)
