@@ -14,6 +14,7 @@ import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -387,10 +388,28 @@ class ParallelLLM(nn.Module):
             else:
                 continue
             ad = self.adaptor[io_name]
-            for feat, (bidx, start, length) in zip(feats, kwargs[f"{io_name}_indices"].tolist()):
-                n = min(length, feat.shape[0])
-                if n > 0:
-                    ops.gemm(feat[:n], ad.weight, bias=ad.bias, out=input_embeds[bidx, start:start + n])
+            entries = [(b_, s_, min(l_, f_.shape[0]), f_) for f_, (b_, s_, l_) in zip(feats, kwargs[f"{io_name}_indices"].tolist())]
+            entries = [e for e in entries if e[2] > 0]
+            if len(entries) == 1:
+                bidx, start, n, feat = entries[0]
+                ops.gemm(feat[:n], ad.weight, bias=ad.bias, out=input_embeds[bidx, start:start + n])
+            elif entries:
+                # several clips / windows: ONE adaptor GEMM over all their tokens and ONE row gather that drops every projected row
+                # at its (b, start + j) -- not a GEMM launch per entry (the reference loops, lm/parallel.py:277-282)
+                B_, T_, H_ = input_embeds.shape
+                whole = isinstance(feats, torch.Tensor) and feats.dim() == 3 and len(entries) == feats.shape[0] \
+                    and all(e[2] == feats.shape[1] for e in entries)
+                rows = feats.reshape(-1, feats.shape[-1]) if whole else torch.cat([e[3][:e[2]] for e in entries])
+                proj = ops.gemm(rows.contiguous(), ad.weight, bias=ad.bias)
+                plan = np.arange(B_ * T_, dtype=np.int64)
+                off = 0
+                for bidx, start, n, _ in entries:
+                    if not (0 <= bidx < B_ and 0 <= start and start + n <= T_):
+                        raise IndexError(f"{io_name}_indices entry ({bidx}, {start}, {n}) outside input_ids [{B_}, {T_}]")
+                    plan[bidx * T_ + start: bidx * T_ + start + n] = -(np.arange(off, off + n) + 2)
+                    off += n
+                plan_d = torch.from_numpy(plan.astype(np.int32)).to(self.device, non_blocking=True)
+                input_embeds = ops.gather_rows(input_embeds.view(B_ * T_, H_), proj, plan_d, B_ * T_).view(B_, T_, H_)
         return input_embeds
 
     @torch.no_grad()
