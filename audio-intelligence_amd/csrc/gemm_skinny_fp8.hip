@@ -66,15 +66,23 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     // SwiGLU epilogue (NT == 2): workgroup b owns gate rows [64 j + 16 t, +16) and the matching up rows 32 further
     // (j = b >> 1, t = b & 1) of the 32-row interleaved gate/up weight: 16-row granularity keeps the per-CU byte share even
     const bool pair = (NT == 2) && p.swiglu_out;
-    const int TR = pair ? 16 : p.tile_rows;
-    const int n_base = pair ? ((int)(blockIdx.x >> 1) * 64 + (int)(blockIdx.x & 1) * 16) : (int)blockIdx.x * (NT * TR);
+    const int TR = p.tile_rows;                        // pair mode: gate rows (= up rows) per workgroup, <= 16
+    const int g0 = (int)blockIdx.x * TR;               // pair mode: first gate index of this workgroup, gate g = W row 64 (g >> 5) + (g & 31)
+    const int n_base = pair ? 0 : (int)blockIdx.x * (NT * TR);
     const int cr = c16 < TR ? c16 : TR - 1;           // lanes past the share re-read its last row (same line: no extra traffic), their results are dropped
 
     const char* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n_base + (pair ? t * 32 + c16 : t * TR + cr);
-        n = n < p.N ? n : p.N - 1;
+        int n;
+        if (pair) {
+            int g = g0 + cr;
+            g = g < (p.N >> 1) ? g : (p.N >> 1) - 1;
+            n = ((g >> 5) << 6) + (g & 31) + t * 32;
+        } else {
+            n = n_base + t * TR + cr;
+            n = n < p.N ? n : p.N - 1;
+        }
         wrow[t] = p.W + (long long)n * p.ldw;
     }
     const char* arow[MT];
@@ -259,8 +267,10 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
                     u += red[((((w * NT + nt + NG) * MT + mt) * 64 + ln) << 2) + reg];
                 }
                 const int mrow = 4 * (ln >> 4) + reg, m = mt * 16 + mrow;
-                const int ng = n_base + (pair ? 0 : nt * 16) + (ln & 15);
-                if (ng + 32 < p.N + 1 && m < p.M) {
+                const int gi = g0 + (ln & 15);                                   // pair form: gate index
+                const int ng = pair ? ((gi >> 5) << 6) + (gi & 31) : n_base + nt * 16 + (ln & 15);   // gate row index inside W
+                const bool live = pair ? ((ln & 15) < TR && gi < (p.N >> 1)) : (ng + 32 < p.N + 1);
+                if (live && m < p.M) {
                     const float r = row_scale(mt, mrow);
                     g *= r * p.wscale[ng];
                     u *= r * p.wscale[ng + 32];
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
 
 template <int NT, int MT>
 void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
-    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)(p.N / 32) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(512);
+    const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)cdiv(p.N / 2, p.tile_rows) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(512);
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
     if constexpr (MT == 1) {
         const size_t img = (size_t)p.a_rows * p.K * 2;
@@ -343,6 +353,17 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     const int amode = a->a_norm_w ? A_RMSNORM : A_PLAIN;
     p.a_rows = a->M <= 8 ? 8 : 16;
     p.tile_rows = 16;
+    if (sw_out) {
+        // SwiGLU pairs: a workgroup owns TR gate rows + their up rows.  TR = 16 cuts 18 944 gate rows into 1184 workgroups = 4.6 per CU
+        // (the last round 62 % full); pick the TR <= 16 whose ceil(units / CUs) * TR is smallest (15 -> 1263 units = 4.93 per CU)
+        const int cus = afhip_cu_count(), gates = a->N / 2;
+        int best = 16, best_cost = cdiv(cdiv(gates, 16), cus) * 16;
+        for (int tr = 15; tr >= 12; --tr) {
+            const int cost = cdiv(cdiv(gates, tr), cus) * tr;
+            if (cost < best_cost) { best_cost = cost; best = tr; }
+        }
+        p.tile_rows = best;
+    }
     int nt_narrow = 1;
     if (!wide && !sw_out) {                 // one equal share of weight rows per CU (gemm_skinny.hip)
         const int rpw = cdiv(a->N, afhip_cu_count());
