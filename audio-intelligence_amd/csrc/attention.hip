@@ -505,11 +505,13 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     const dim3 grid((unsigned)(p.n_xt * a->n_q * a->B)), block(256);
     static int nbuf = -1;
     if (nbuf < 0) { const char* e = getenv("AFHIP_ATTN_NBUF"); nbuf = (e && e[0] == '1') ? 1 : 2; }   // A/B switch
-    const size_t lds = (size_t)nbuf * 2 * KT * a->hd * sz;     // stages of (K tile + V tile)
+    size_t lds = (size_t)nbuf * 2 * KT * a->hd * sz;     // stages of (K tile + V tile)
+    { static long pad = -1; if (pad < 0) { const char* e = getenv("AFHIP_ATTN_LDS_PAD"); pad = e ? atol(e) : 0; } lds += (size_t)pad; }   // occupancy experiment
     {
         static unsigned long long attr_done = 0;
         if (afhip_first_use_on_device(&attr_done)) {
             (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 2);
+            (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)attn_kernel<float, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 64 * 4);
             (void)hipFuncSetAttribute((const void*)attn_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 4);
         }
