@@ -40,7 +40,7 @@ class AttnArgs(C.Structure):
                 ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
                 ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
                 ("q_prescaled", C.c_int), ("new_k", C.c_void_p), ("new_v", C.c_void_p), ("new_kv_batch_stride", C.c_longlong),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p), ("row_off", C.c_void_p)]
 
 
 class EncoderWeights(C.Structure):
@@ -113,6 +113,7 @@ SIGNATURES = {
     "afhip_attention": (_I, [C.POINTER(AttnArgs), _P]),
     "afhip_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderWeights), _I]),
     "afhip_encoder_forward": (_I, [C.POINTER(EncoderWeights), _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "afhip_encoder_forward_ragged": (_I, [C.POINTER(EncoderWeights), _P, _P, _P, _I, _P, _P, _Z, _P]),
     "afhip_llm_workspace_bytes": (_Z, [C.POINTER(LlmWeights), _I, _I, _I]),
     "afhip_llm_forward": (_I, [C.POINTER(LlmWeights), _P, _I, _I, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),
     "afhip_llm_forward_ragged": (_I, [C.POINTER(LlmWeights), _P, _I, _P, _I, C.POINTER(KvCache), _P, _P, _Z, _P]),

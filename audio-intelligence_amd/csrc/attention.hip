@@ -39,6 +39,8 @@ struct AttnP {
     int* ticket;            // split mode: in-launch merge by the last-arriving key-range workgroup (afhip.h); NULL = separate pass
     const int32_t* seq_pos; // split mode: per-sequence position of the token being generated, read on the DEVICE (Tk_b = seq_pos[b] + 1,
                             // RoPE row, append slot); p.Tk is then only the host's upper bound that sized the grid.  NULL = uniform p.Tk
+    const int32_t* row_off; // packed (ragged) self-attention: sequence b's rows start at row row_off[b] of q / k / v / o and it has key_len[b]
+                            // queries and keys; p.Tq / p.Tk are then only the upper bound that sized the grid.  NULL = [B, T] batches
     unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
 };
 
@@ -96,13 +98,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int split = p.key_split > 0 ? xt : 0;
     const int q0 = p.key_split > 0 ? 0 : xt * QT;
     const int qrow = q0 + wave * 32 + fr;                 // this lane's query
-    const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+    // [B, T] batches: sequence b at b * batch stride, p.Tq queries.  Packed batches: at row row_off[b], key_len[b] queries (= keys)
+    long long q_off = (long long)b * p.q_bs, kv_off = (long long)b * p.kv_bs, o_off = (long long)b * p.o_bs;
+    int Tq = p.Tq;
+    if (p.row_off) {
+        const long long r = p.row_off[b];
+        q_off = r * p.ld_q; kv_off = r * p.ld_kv; o_off = r * p.ld_o;
+        Tq = p.key_len[b];
+        if (q0 >= Tq) return;                             // query tile past this sequence (workgroup-uniform, before any barrier)
+    }
+    const int qrow_c = qrow < Tq ? qrow : Tq - 1;
     const int qpos = p.q_pos0 + qrow;
     const int wave_qpos_min = p.q_pos0 + q0 + wave * 32;   // smallest query position held by this wave
 
-    const char* qb = p.q + ((long long)b * p.q_bs + (long long)hq * p.q_hs) * SZ;
-    const char* kb = p.k + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
-    const char* vb = p.v + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * SZ;
+    const char* qb = p.q + (q_off + (long long)hq * p.q_hs) * SZ;
+    const char* kb = p.k + (kv_off + (long long)hkv * p.kv_hs) * SZ;
+    const char* vb = p.v + (kv_off + (long long)hkv * p.kv_hs) * SZ;
 
     int klen = p.Tk;
     if (p.seq_pos) { const int tk = p.seq_pos[b] + 1; klen = tk < klen ? tk : klen; }   // wave-uniform (b is per workgroup)
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     if (p.key_len) { const int kl = p.key_len[b]; klen = kl < klen ? kl : klen; }
     int kend = klen;                                       // keys this workgroup must visit
     if (p.causal) {
-        const int last = p.q_pos0 + (q0 + QT - 1 < p.Tq - 1 ? q0 + QT - 1 : p.Tq - 1) + 1;
+        const int last = p.q_pos0 + (q0 + QT - 1 < Tq - 1 ? q0 + QT - 1 : Tq - 1) + 1;
         kend = last < kend ? last : kend;
     }
     int kbeg = 0;
@@ -165,7 +176,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             const int c = tid + 256 * i;
             const int row = c / KCPR, cc = c % KCPR;
             int key = k0 + row;
-            key = key < tk_b ? key : tk_b - 1;
+            key = key < klen ? key : klen - 1;       // masked keys re-read the last live row: their P is 0, and 0 x (whatever sits behind the
+                                                     // sequence -- padding, the next packed clip, stale workspace with NaNs) must stay 0
             const long long off = ((long long)key * p.ld_kv) * SZ + cc * 16;
             rk[i] = ld16(kb + off);
             rv[i] = ld16(vb + off);
@@ -401,8 +413,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         return;
     }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < p.Tq) {
-        T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
+    if (qrow < Tq) {
+        T* op = reinterpret_cast<T*>(p.o) + o_off + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -483,6 +495,8 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
     p.ticket = a->key_split > 0 ? a->split_ticket : nullptr;
     p.seq_pos = a->seq_pos;
+    p.row_off = a->row_off;
+    if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
     if (a->seq_pos) AFHIP_CHECK(a->key_split > 0, "afhip_attention: seq_pos needs the split-context (decode) form, key_split > 0");
     if (a->new_k) {
         AFHIP_CHECK(a->key_split > 0 && a->new_v && a->rope_cos && a->rope_sin, "afhip_attention: fused RoPE/append needs key_split > 0, new_v and the cos/sin rows");

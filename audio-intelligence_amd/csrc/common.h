@@ -47,6 +47,11 @@ static inline size_t dtype_size(int dt) { return dt == AFHIP_BF16 ? 2 : 4; }
 
 // compute units of the current device (cached per process; 256 on MI355X)
 int afhip_cu_count();
+// packed (ragged) encoder batches, norm.hip (C++ linkage: internal to the library)
+int afhip_ragged_row_offsets(const int32_t* len, int32_t* row_off, int B, hipStream_t s);
+int afhip_ragged_pack_rows(const void* src, void* dst, const int32_t* row_off, const int32_t* len, int B, int T, int row_bytes, hipStream_t s);
+int afhip_ragged_avgpool_ln(const void* x, const int32_t* row_off, const int32_t* len, const void* w, const void* b, void* y, int B, int Tout,
+                            int D, float eps, int dtype, hipStream_t s);
 
 // ---- element access in f32 regardless of storage type ----
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -21,6 +21,7 @@ struct EncWs {
     char* att;   // [B*Tp, d]
     float* part; // [d/64][B*Tp][2] row (sum, sum of squares) partials of the stored residual stream (LayerNorm-folded mode)
     float* stats;// [B*Tp][2] row (mean, rstd)
+    int32_t* roff; // [B + 1] first packed row of each clip (ragged forward)
     size_t total;
 };
 
@@ -41,6 +42,7 @@ EncWs carve(const afhip_encoder_weights* w, int B, char* base) {
     ws.att = take(rows * d * sz);
     ws.part = (float*)take((d / 64 + 1) * rows * 2 * sizeof(float));
     ws.stats = (float*)take(rows * 2 * sizeof(float));
+    ws.roff = (int32_t*)take(((size_t)B + 1) * sizeof(int32_t));
     ws.total = off;
     return ws;
 }
@@ -79,9 +81,11 @@ extern "C" size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, 
     return carve(w, B, nullptr).total;
 }
 
-extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, int B,
-                                     void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+namespace {
+// len_host != nullptr: packed (ragged) forward, see afhip.h afhip_encoder_forward_ragged
+int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, const int32_t* len_host, int B,
+                         void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
+                         void* stream) {
     AFHIP_CHECK(w && mel_btc && out && workspace, "afhip_encoder_forward: null pointer");
     AFHIP_CHECK(B > 0, "afhip_encoder_forward: bad batch %d", B);
     AFHIP_CHECK(w->dtype == AFHIP_F32 || w->dtype == AFHIP_BF16, "afhip_encoder_forward: bad dtype %d", w->dtype);
@@ -100,7 +104,9 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
     const int dt = w->dtype;
     const size_t sz = dtype_size(dt);
     const int d = w->d_model, f = w->ffn_dim, Tp = w->max_pos, Tm = 2 * w->max_pos, nm = w->n_mels;
-    const int rows = B * Tp;
+    int rows = B * Tp;
+    char* h = ws.h;
+    char* att = ws.att;
     int rc;
 
     // conv stem (modeling_whisper.py:690-696)
@@ -108,6 +114,25 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
     if ((rc = gemm(ws.big, w->conv2_w, w->conv2_b, w->pos_emb, ws.h, rows, d, 3 * d, d, d, d, dt, AFHIP_ACT_GELU, Tp, s, Tm, Tp, 2, d))) return rc;
     if (hidden_out && hidden_layer == -1) {
         if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
+    }
+
+    const bool ragged = len_host != nullptr;
+    if (ragged) {
+        // keep the valid positions only: every layer below runs on M = sum of lengths rows.  The stem ran on the full padded mel, so
+        // the last valid position saw the frames behind it exactly as in the unpacked forward.
+        long long tot = 0;
+        for (int b = 0; b < B; ++b) {
+            AFHIP_CHECK(len_host[b] >= 0 && len_host[b] <= Tp, "afhip_encoder_forward_ragged: feat_len[%d] = %d outside [0, %d]", b, len_host[b], Tp);
+            tot += len_host[b];
+        }
+        if ((rc = afhip_ragged_row_offsets(feat_len, ws.roff, B, s))) return rc;
+        if (tot == 0) {
+            if (hipMemsetAsync(out, 0, (size_t)B * (Tp / 2) * d * sz, s) != hipSuccess) { afhip_set_error("encoder: memset failed"); return AFHIP_ERR_LAUNCH; }
+            return 0;
+        }
+        if ((rc = afhip_ragged_pack_rows(ws.h, ws.att, ws.roff, feat_len, B, Tp, (int)(d * sz), s))) return rc;
+        h = ws.att; att = ws.h;          // the packed stream lives in the (equally sized) attention buffer from here on
+        rows = (int)tot;
     }
 
     // LayerNorm-folded mode (bf16, ping-pong-GEMM shapes): the two LayerNorms of a layer never write a normalised copy of the
@@ -121,8 +146,9 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
                     d % 256 == 0 && f % 256 == 0;
     for (int l = 0; l < w->n_layers; ++l) {
         afhip_attn_args a = {};
-        a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = ws.att;
+        a.q = ws.qkv; a.k = ws.qkv + (size_t)d * sz; a.v = ws.qkv + (size_t)2 * d * sz; a.out = att;
         a.key_len = feat_len;
+        a.row_off = ragged ? ws.roff : nullptr;
         a.B = B; a.Tq = Tp; a.Tk = Tp; a.n_q = w->n_heads; a.n_kv = w->n_heads; a.hd = hd;
         a.ld_q = 3 * d; a.ld_kv = 3 * d; a.ld_o = d;
         a.q_batch_stride = (long long)Tp * 3 * d; a.kv_batch_stride = (long long)Tp * 3 * d; a.o_batch_stride = (long long)Tp * d;
@@ -132,12 +158,12 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
         a.q_prescaled = (fold && !f8 && w->q_prescaled) ? 1 : 0;
         if (f8) {
             float* sc = ws.stats;                           // [rows] row scales of the activation being multiplied
-            if ((rc = afhip_quant_rows(ws.h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = afhip_quant_rows(h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
             if ((rc = gemm8(ws.ln, sc, w->qkv_w8[l], w->qkv_s8[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, 3 * d, 0, AFHIP_ACT_NONE, s))) return rc;
             if ((rc = afhip_attention(&a, s))) return rc;
-            if ((rc = afhip_quant_rows(ws.att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
-            if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
-            if ((rc = afhip_quant_rows(ws.h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = afhip_quant_rows(att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
+            if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], h, h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
+            if ((rc = afhip_quant_rows(h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
             if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
             // fc2 stays bf16: its input is the [rows, ffn] GELU output, and a per-row quantisation pass over it (492 MB read +
             // 246 MB written, 109 us at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us); the other three inputs are
@@ -146,36 +172,50 @@ extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void*
             if (fc2_f8 < 0) { const char* e = getenv("AFHIP_FP8_FC2"); fc2_f8 = (e && e[0] == '1') ? 1 : 0; }
             if (fc2_f8) {
                 if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
-                if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
+                if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
             } else {
-                if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+                if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], h, h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
             }
         } else if (fold) {
-            if (l == 0 && (rc = afhip_row_stats(ws.h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
-            if ((rc = gemm(ws.h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+            if (l == 0 && (rc = afhip_row_stats(h, rows, d, 1e-5f, dt, ws.stats, s))) return rc;   // layer 0 reads the conv stem
+            if ((rc = gemm(h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
                            ws.stats, w->qkv_cs[l], w->qkv_bf[l], nullptr))) return rc;
             if ((rc = afhip_attention(&a, s))) return rc;
-            if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+            if ((rc = gemm(att, w->out_w[l], w->out_b[l], h, h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
                            nullptr, nullptr, nullptr, ws.part))) return rc;
             if ((rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats, s))) return rc;
-            if ((rc = gemm(ws.h, w->fc1_wf[l], nullptr, nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s, 0, 0, 0, 0,
+            if ((rc = gemm(h, w->fc1_wf[l], nullptr, nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s, 0, 0, 0, 0,
                            ws.stats, w->fc1_cs[l], w->fc1_bf[l], nullptr))) return rc;
             const bool last = l + 1 == w->n_layers;
-            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], h, h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
                            nullptr, nullptr, nullptr, last ? nullptr : ws.part))) return rc;
             if (!last && (rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats, s))) return rc;
         } else {
-            if ((rc = afhip_layernorm(ws.h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+            if ((rc = afhip_layernorm(h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
             if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
             if ((rc = afhip_attention(&a, s))) return rc;
-            if ((rc = gemm(ws.att, w->out_w[l], w->out_b[l], ws.h, ws.h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
-            if ((rc = afhip_layernorm(ws.h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+            if ((rc = gemm(att, w->out_w[l], w->out_b[l], h, h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            if ((rc = afhip_layernorm(h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
             if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
-            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], ws.h, ws.h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], h, h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
         }
         if (hidden_out && hidden_layer == l) {
-            if (hipMemcpyAsync(hidden_out, ws.h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
+            if (hipMemcpyAsync(hidden_out, h, (size_t)rows * d * sz, hipMemcpyDeviceToDevice, s) != hipSuccess) { afhip_set_error("encoder: hidden copy failed"); return AFHIP_ERR_LAUNCH; }
         }
     }
-    return afhip_avgpool_ln(ws.h, w->lnf_w, w->lnf_b, out, B, Tp / 2, d, 1e-5f, dt, s);
+    if (ragged) return afhip_ragged_avgpool_ln(h, ws.roff, feat_len, w->lnf_w, w->lnf_b, out, B, Tp / 2, d, 1e-5f, dt, s);
+    return afhip_avgpool_ln(h, w->lnf_w, w->lnf_b, out, B, Tp / 2, d, 1e-5f, dt, s);
+}
+}  // namespace
+
+extern "C" int afhip_encoder_forward(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, int B,
+                                     void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return encoder_forward_impl(w, mel_btc, feat_len, nullptr, B, out, hidden_out, hidden_layer, workspace, workspace_bytes, stream);
+}
+
+extern "C" int afhip_encoder_forward_ragged(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, const int32_t* feat_len_host,
+                                            int B, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    AFHIP_CHECK(feat_len && feat_len_host, "afhip_encoder_forward_ragged: feat_len is needed on the device and on the host");
+    return encoder_forward_impl(w, mel_btc, feat_len, feat_len_host, B, out, nullptr, -1, workspace, workspace_bytes, stream);
 }

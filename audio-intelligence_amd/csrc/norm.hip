@@ -31,14 +31,28 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 }
 
 // MODE 0: LayerNorm(x[row]); MODE 1: LayerNorm(round_T((x[2row] + x[2row+1]) / 2)) within a clip of Tout rows.
+// MODE 2: MODE 1 on PACKED clips (encoder.hip ragged forward): output row (b, t) = row / Tout, row % Tout pools x rows
+// row_off[b] + 2t, + 2t + 1 when t < (len[b] - 2) / 2 + 1 (the rows the reference keeps, audio.py:1163-1187), zeros otherwise.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                         const T* __restrict__ b, T* __restrict__ y, int rows, int D,
-                                                        float eps) {
+                                                        float eps, const int* __restrict__ row_off = nullptr,
+                                                        const int* __restrict__ len = nullptr, int Tout = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 3;
+    long long src = 2 * (long long)row;
+    if (MODE == 2) {
+        const int bi = row / Tout, t = row - bi * Tout, L = len[bi];
+        const int n_out = L >= 2 ? (L - 2) / 2 + 1 : 0;
+        if (t >= n_out) {                                   // wave-uniform: a wave owns one row
+            float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int c = lane; c < nch; c += 64) store8<T>(y + (long long)row * D + c * 8, z);
+            return;
+        }
+        src = (long long)row_off[bi] + 2 * t;
+    }
     float v[MAXC][8];
     float s = 0.f;
 #pragma unroll
@@ -49,8 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                 load8<T>(x + (long long)row * D + c * 8, v[i]);
             } else {
                 float a[8], bb[8];
-                load8<T>(x + (long long)(2 * row) * D + c * 8, a);
-                load8<T>(x + (long long)(2 * row + 1) * D + c * 8, bb);
+                load8<T>(x + src * D + c * 8, a);
+                load8<T>(x + (src + 1) * D + c * 8, bb);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = to_f32<T>(from_f32<T>((a[e] + bb[e]) * 0.5f));
             }
@@ -217,6 +231,52 @@ extern "C" int afhip_avgpool_ln(const void* x, const void* w, const void* b, voi
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((layernorm_kernel<bf16, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)y, rows, D, eps),
                hipLaunchKernelGGL((layernorm_kernel<float, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const float*)x, (const float*)w, (const float*)b, (float*)y, rows, D, eps));
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- packed (ragged) encoder batches: helpers of encoder.hip's afhip_encoder_forward_ragged (C++ linkage, not part of the ABI) ----
+namespace {
+// row_off[b] = sum of len[0..b): B is small (one wave scans it)
+__global__ void row_offsets_kernel(const int* __restrict__ len, int* __restrict__ row_off, int B) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < B; ++i) { row_off[i] = acc; acc += len[i]; }
+        row_off[B] = acc;
+    }
+}
+// dst[row_off[b] + t] = src[b, t] for t < len[b]: one wave per source row, 16 B per lane
+__global__ __launch_bounds__(256) void pack_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int* __restrict__ row_off,
+                                                        const int* __restrict__ len, int B, int T, int row_bytes) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long long)B * T) return;
+    const int b = (int)(r / T), t = (int)(r - (long long)b * T);
+    if (t >= len[b]) return;
+    const char* s = src + r * row_bytes;
+    char* d = dst + ((long long)row_off[b] + t) * row_bytes;
+    for (int c = lane * 16; c < row_bytes; c += 64 * 16) *reinterpret_cast<u32x4*>(d + c) = *reinterpret_cast<const u32x4*>(s + c);
+}
+}  // namespace
+
+int afhip_ragged_row_offsets(const int32_t* len, int32_t* row_off, int B, hipStream_t s) {
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(64), 0, s, len, row_off, B);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+int afhip_ragged_pack_rows(const void* src, void* dst, const int32_t* row_off, const int32_t* len, int B, int T, int row_bytes, hipStream_t s) {
+    AFHIP_CHECK(row_bytes % 16 == 0, "ragged pack: rows must be multiples of 16 bytes");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)cdiv(B * T, 4)), dim3(256), 0, s, (const char*)src, (char*)dst, row_off, len, B, T, row_bytes);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+int afhip_ragged_avgpool_ln(const void* x, const int32_t* row_off, const int32_t* len, const void* w, const void* b, void* y, int B, int Tout,
+                            int D, float eps, int dtype, hipStream_t s) {
+    const int rows = B * Tout;
+    if (int e = check_row("afhip_ragged_avgpool_ln", rows, D, dtype)) return e;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((layernorm_kernel<bf16, 2>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)y, rows, D, eps, row_off, len, Tout),
+               hipLaunchKernelGGL((layernorm_kernel<float, 2>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const float*)x, (const float*)w, (const float*)b, (float*)y, rows, D, eps, row_off, len, Tout));
     AFHIP_LAUNCH_CHECK();
     return 0;
 }

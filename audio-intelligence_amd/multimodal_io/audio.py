@@ -9,6 +9,7 @@ encode_batch is handed to the kernels as the per-clip length vector the referenc
 from typing import List, Tuple
 
 import numpy as np
+import os
 import torch
 
 from .abs_io import AbsIO
@@ -98,7 +99,12 @@ class ContinuousAudioIO(AbsIO):
             raise RuntimeError("worker copy has no encoder (copy_for_worker)")
         input_mel_lengths = length.to(torch.long).cpu() * 4 - 1
         feat_len, out_len = self.model._get_feat_extract_output_lengths(input_mel_lengths)
-        out = self.model.encode_btc(batch_data, feat_len=feat_len.clamp(max=self.model.config.max_source_positions))
+        Tp = self.model.config.max_source_positions
+        feat_len = feat_len.clamp(max=Tp)
+        # clips of different lengths (self-test convention): the encoder runs on the valid positions only, packed -- the rows
+        # returned below are bit-identical to the padded forward, the ones it would compute from padding are trimmed anyway
+        ragged = bool((feat_len < Tp).any()) and os.environ.get("AFHIP_ENCODER_RAGGED", "1") != "0"
+        out = self.model.encode_btc(batch_data, feat_len=feat_len, ragged=ragged)
         return [out[i, : int(out_len[i])] for i in range(out.shape[0])]
 
     @torch.no_grad()

@@ -259,9 +259,13 @@ class AFWhisperEncoder(nn.Module):
         output_lengths = (input_lengths - 2) // 2 + 1
         return input_lengths, output_lengths
 
-    def encode_btc(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, hidden_layer: Optional[int] = None):
+    def encode_btc(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, hidden_layer: Optional[int] = None,
+                   ragged: bool = False):
         """mel [B,3000,128] (model dtype, GPU) + optional per-clip key length [B] -> [B,750,d].
-        `hidden_layer` (-1 = conv stem, l = output of layer l) additionally returns that [B,1500,d] state."""
+        `hidden_layer` (-1 = conv stem, l = output of layer l) additionally returns that [B,1500,d] state.
+        `ragged=True` (needs feat_len): the layers run on the valid positions only, packed (afhip_encoder_forward_ragged); rows
+        t < (feat_len - 2) // 2 + 1 of each clip are bit-identical to the padded forward, the rows behind them -- which callers
+        trim (audio.py:1163-1187) -- are zero instead of values computed from padding."""
         lib = L.lib()
         pk = self.pack()
         cfg = self.config
@@ -278,6 +282,13 @@ class AFWhisperEncoder(nn.Module):
         if hidden_layer is not None:
             hid = torch.empty((B, cfg.max_source_positions, cfg.d_model), dtype=self.dtype, device=self.device)
         ws = self._workspace(B)
+        if ragged:
+            if feat_len is None or hidden_layer is not None:
+                raise ValueError("ragged=True needs feat_len and cannot return hidden states")
+            fl_host = feat_len.detach().to(device="cpu", dtype=torch.int32).contiguous()
+            L.check(lib.afhip_encoder_forward_ragged(C.byref(pk.w), L.ptr(mel_btc), L.ptr(fl), fl_host.data_ptr(), B, L.ptr(out),
+                                                     L.ptr(ws), ws.numel(), L.stream_ptr()))
+            return out
         L.check(lib.afhip_encoder_forward(C.byref(pk.w), L.ptr(mel_btc), L.ptr(fl), B, L.ptr(out), L.ptr(hid),
                                           hidden_layer if hidden_layer is not None else -1, L.ptr(ws), ws.numel(), L.stream_ptr()))
         return (out, hid) if hidden_layer is not None else out

@@ -212,6 +212,12 @@ typedef struct {
      * one captured hipGraph of a decode step be replayed for every token (nothing position-dependent is baked into kernel
      * arguments) and what a ragged batch (AF3 generate() with left / right padded prompts) needs. */
     const int32_t* seq_pos;
+    /* Packed (ragged) self-attention, key_split == 0 and causal == 0 only: row_off [B] int32 (device).  Sequence b's rows start at row
+     * row_off[b] of q / k / v / out (row pitches ld_q / ld_kv / ld_o; the batch strides are ignored) and it has key_len[b] queries
+     * and keys (key_len is then mandatory); Tq == Tk is the upper bound that sizes the grid, query tiles past a sequence's length
+     * exit.  This is how a batch of clips of different lengths runs on M = sum of lengths rows instead of B * max length
+     * (afhip_encoder_forward_ragged).  NULL = [B, T] batches. */
+    const int32_t* row_off;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 
@@ -258,6 +264,16 @@ size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 int afhip_encoder_forward(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, int B,
                           void* out, void* hidden_out, int hidden_layer, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* The same forward for a batch of clips of DIFFERENT lengths, on packed rows: after the conv stem (which runs on the full padded
+ * mel, so the last valid position still sees the frames behind it exactly as in the reference) only the feat_len[b] valid
+ * positions of each clip are kept, and every layer -- GEMMs, LayerNorm statistics, attention -- runs on M = sum_b feat_len[b] rows
+ * instead of B * max_pos.  Per valid position the arithmetic is the one afhip_encoder_forward performs (same kernels, same K
+ * order, same key tiles): rows t < (feat_len[b] - 2) / 2 + 1 of out[b] are bit-identical to it; the rows behind them, which the
+ * reference computes from padded positions and its callers trim (audio.py:1163-1187), are ZERO here.
+ * feat_len [B] int32 on the device and feat_len_host, the same values on the host (the host sizes the launches from them);
+ * 0 <= feat_len[b] <= max_pos.  Workspace as afhip_encoder_workspace_bytes(w, B). */
+int afhip_encoder_forward_ragged(const afhip_encoder_weights* w, const void* mel_btc, const int32_t* feat_len, const int32_t* feat_len_host,
+                                 int B, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LLM (Qwen2 decoder stack + UALM head).  Replaces ParallelLLM._step (lm/parallel.py:570-597) over

@@ -239,3 +239,62 @@ def test_full_size_batch_consistency_bf16():
     for b in range(5):
         single = enc.encode_btc(torch.cat([mels[b:b + 1], mel]).contiguous())      # B = 2: same kernels as the batch
         assert torch.equal(batch[b], single[0]), f"clip {b}: batched != alone"
+
+
+def _kept(feat_len):
+    return (feat_len - 2) // 2 + 1 if feat_len >= 2 else 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ragged_packed_forward_keeps_the_padded_forwards_bits_tiny(dtype):
+    """afhip_encoder_forward_ragged (layers on M = sum of lengths packed rows) against the padded forward with the same key
+    lengths: the rows the reference's callers keep (audio.py:1163-1187) must be BIT-identical -- same kernels, same K order,
+    same key tiles per row -- and the rows behind them zero.  Lengths: full, short, odd, one tile, 2, 1 and 0 positions."""
+    _need_gpu()
+    enc = _tiny_encoder(dtype)
+    g = torch.Generator().manual_seed(5)
+    lens = torch.tensor([1500, 250, 777, 128, 2, 1, 0, 1499], dtype=torch.int32)
+    mel = (torch.randn(len(lens), 3000, 128, generator=g) * 0.4).to(DEV, dtype)
+    ragged = enc.encode_btc(mel, feat_len=lens, ragged=True)
+    padded = enc.encode_btc(mel, feat_len=lens)
+    assert list(ragged.shape) == [len(lens), 750, enc.config.d_model]
+    for b, n in enumerate(lens.tolist()):
+        k = _kept(n)
+        assert torch.equal(ragged[b, :k], padded[b, :k]), f"clip {b} (len {n}): kept rows differ"
+        assert bool((ragged[b, k:] == 0).all()), f"clip {b}: rows behind the kept ones must be zero"
+    assert bool(torch.isfinite(ragged.float()).all())
+
+
+def test_ragged_packed_forward_full_shape_bf16_and_encode_batch():
+    """The same at the full encoder shape in bf16 (LayerNorm-folded ping-pong GEMMs on the packed rows), and through
+    ContinuousAudioIO.encode_batch, which takes the packed path by itself when the lengths differ."""
+    _need_gpu()
+    from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+    from audio_intelligence_amd.utils import synthetic as syn
+    cfg = oracle.afwhisper.default_config()
+    enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(cfg))
+    enc.load_state_dict(syn.synth_state_dict(syn.encoder_param_shapes(cfg), fc.SEED_ENC_FULL), strict=True)
+    enc = enc.to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(6)
+    lens = torch.tensor([1500, 333, 1000, 64, 1201, 500], dtype=torch.int32)
+    mel = (torch.randn(len(lens), 3000, 128, generator=g) * 0.3).to(DEV, torch.bfloat16)
+    # the workspace is poisoned first: whatever sits behind a sequence's last row (stale rows of an earlier, larger batch) must
+    # not leak into it through the masked keys of its last key tile (0 x NaN)
+    enc._workspace(len(lens)).view(torch.bfloat16).fill_(float("nan"))
+    ragged = enc.encode_btc(mel, feat_len=lens, ragged=True)
+    enc._workspace(len(lens)).view(torch.bfloat16).fill_(float("nan"))
+    padded = enc.encode_btc(mel, feat_len=lens)
+    for b, n in enumerate(lens.tolist()):
+        k = _kept(n)
+        assert bool(torch.isfinite(ragged[b, :k].float()).all()), f"clip {b} (len {n}): non-finite rows"
+        assert torch.equal(ragged[b, :k], padded[b, :k]), f"clip {b} (len {n}): kept rows differ"
+        assert bool((ragged[b, k:] == 0).all())
+    io = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="bfloat16", device=DEV, encoder=enc)
+    length = torch.tensor([750, 167, 500, 32, 600, 250])           # encode_batch: L = 4 length - 1 mel frames -> feat_len = 2 length
+    outs = io.encode_batch(mel, length)
+    feat, out_len = enc._get_feat_extract_output_lengths(length * 4 - 1)
+    ref = enc.encode_btc(mel, feat_len=feat.clamp(max=1500))
+    for b in range(len(lens)):
+        assert outs[b].shape[0] == int(out_len[b])
+        assert torch.equal(outs[b], ref[b, : int(out_len[b])]), f"clip {b}: encode_batch (packed) != padded forward"
