@@ -435,25 +435,47 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
 }
 
-// merge the key-range partials of the split kernel: out = sum_s O_s * 2^((m_s - m) c) / sum_s l_s * 2^((m_s - m) c)
+// merge the key-range partials of the split kernel: out = sum_s O_s * 2^((m_s - m) c) / sum_s l_s * 2^((m_s - m) c).
+// One workgroup per (sequence, head, query row), one thread per output column.  The (max, sum) pairs of the key ranges are staged
+// and turned into weights in LDS once per workgroup, and the O_s loads of eight ranges are issued together before they are
+// accumulated IN RANGE ORDER (same fma chain as a plain loop, so the bits do not depend on the staging): with one dependent
+// load per range the merge of the 118 ranges of a 15 000-key context took 50 us per layer, longer than the attention itself.
+constexpr int CMB_CHUNK = 512;
 template <typename T>
 __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
+    __shared__ float s_w[CMB_CHUNK], s_l[CMB_CHUNK], s_red[4];
     const int row = blockIdx.x;                      // (b, hq, qrow) flattened
     const int qrow = row % p.Tq, hq = (row / p.Tq) % p.n_q, b = row / (p.Tq * p.n_q);
     const int d = threadIdx.x;
     if (p.seq_pos) { const int live = (p.seq_pos[b] + 1 + p.key_split - 1) / p.key_split; n_split = live < n_split ? live : n_split; }
+    auto slot_of = [&](int sp) { return (((long long)sp * p.B + b) * p.n_q + hq) * 32 + qrow; };
     float m = -INFINITY;
-    for (int s = 0; s < n_split; ++s) {
-        const long long slot = (((long long)s * p.B + b) * p.n_q + hq) * 32 + qrow;
-        m = fmaxf(m, p.part_ml[slot * 2]);
-    }
+    for (int sp = d; sp < n_split; sp += HD) m = fmaxf(m, p.part_ml[slot_of(sp) * 2]);
+    m = wave_max(m);
+    if ((d & 63) == 0) s_red[d >> 6] = m;
+    __syncthreads();
+    m = s_red[0];
+    for (int w = 1; w < (HD >> 6); ++w) m = fmaxf(m, s_red[w]);
     float l = 0.f, o = 0.f;
-    for (int s = 0; s < n_split; ++s) {
-        const long long slot = (((long long)s * p.B + b) * p.n_q + hq) * 32 + qrow;
-        const float ms = p.part_ml[slot * 2];
-        const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
-        l += p.part_ml[slot * 2 + 1] * w;
-        o += p.part_o[slot * HD + d] * w;
+    for (int base = 0; base < n_split; base += CMB_CHUNK) {
+        const int n = (n_split - base) < CMB_CHUNK ? (n_split - base) : CMB_CHUNK;
+        __syncthreads();                             // the previous chunk's weights have been consumed
+        for (int i = d; i < n; i += HD) {
+            const long long slot = slot_of(base + i);
+            const float ms = p.part_ml[slot * 2];
+            s_w[i] = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
+            s_l[i] = p.part_ml[slot * 2 + 1];
+        }
+        __syncthreads();
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p.part_o[slot_of(base + i + u) * HD + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { l = fmaf(s_l[i + u], s_w[i + u], l); o = fmaf(v[u], s_w[i + u], o); }
+        }
+        for (; i < n; ++i) { l = fmaf(s_l[i], s_w[i], l); o = fmaf(p.part_o[slot_of(base + i) * HD + d], s_w[i], o); }
     }
     T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
     op[d] = from_f32<T>(l > 0.f ? o / l : 0.f);

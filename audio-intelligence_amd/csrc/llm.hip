@@ -14,6 +14,17 @@ size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 #define DECODE_KEY_SPLIT 128   /* keys per workgroup of the split-context decode attention (multiple of 64); 256 / 128 / 64 measured 3.85 / 3.79 / 3.84 ms per 7B step */
 #endif
 
+// experiment switch: AFHIP_DECODE_KEY_SPLIT = keys per workgroup at run time (a multiple of DECODE_KEY_SPLIT, which sized the workspace)
+static int decode_key_split() {
+    static int ks = 0;
+    if (ks == 0) {
+        const char* e = getenv("AFHIP_DECODE_KEY_SPLIT");
+        const int v = e ? atoi(e) : 0;
+        ks = (v >= DECODE_KEY_SPLIT && v % DECODE_KEY_SPLIT == 0) ? v : DECODE_KEY_SPLIT;
+    }
+    return ks;
+}
+
 struct LlmWs {
     char* x;     // [rows, H] residual stream
     char* nb;    // [rows, H]
@@ -259,7 +270,7 @@ static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, in
             a.ld_q = hd; a.q_head_stride = (long long)rep * hd; a.q_batch_stride = qw;
             a.ld_o = hd; a.o_head_stride = (long long)rep * hd; a.o_batch_stride = (long long)nq * hd;
             a.causal = 0; a.q_pos0 = 0;
-            a.key_split = DECODE_KEY_SPLIT; a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
+            a.key_split = decode_key_split(); a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
             a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
             a.seq_pos = seq_pos;
             a.rope_cos = seq_pos ? w->rope_cos : w->rope_cos + (size_t)pos0 * (hd / 2);
