@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="30-s clips per GPU per step")
     ap.add_argument("--no-decode", action="store_true", help="skip the AF3-7B decode leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp8 / mixed-length encoder legs (PMC passes: only the headline kernels run)")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--workload", choices=["encoder", "long_audio"], default="encoder",
                     help="encoder = BASELINE configs[1] (the headline); long_audio = configs[3]: 4 x 10-min clips, windows sharded over the ranks, one RCCL all-gather")
@@ -487,52 +488,54 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     enc_ms = ev0.elapsed_time(ev1) / 3
-    # BASELINE config 5 evidence (never the headline `value`): the same encoder batch with the four projections of every layer on
-    # e4m3 operands (afhip_gemm a_fp8: block-scaled MFMA, 2x the bf16 rate; activations quantised per row, LayerNorm fused)
-    ref_out = enc.encode_btc(mel)
-    enc.enable_fp8(True)
-    out8 = enc.encode_btc(mel)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(3):
-        enc.encode_btc(mel)
-    ev1.record()
-    torch.cuda.synchronize()
-    enc8_ms = ev0.elapsed_time(ev1) / 3
-    d8 = (out8.float() - ref_out.float()).abs()
-    enc8 = {"encoder_ms": enc8_ms, "encoder_audio_s_per_s": B * 30.0 / (enc8_ms * 1e-3), "speedup_vs_bf16": enc_ms / enc8_ms,
-            "vs_bf16_output_max_abs": float(d8.max()), "vs_bf16_output_mean_abs": float(d8.mean()),
-            "what": "e4m3 x e4m3 MFMA GEMMs for qkv / out / fc1 (per-row activation scales from a fused LayerNorm + quantise pass, per-channel weight scales, f32 accumulate); fc2, the residual stream and attention stay bf16"}
-    enc.enable_fp8(False)
-    del ref_out, out8, d8
-    # BASELINE config 2, second run: the same 32 clips with mixed 5-30 s lengths in the self-test convention
-    # (length = after-conv length -> key-padding mask per clip, audio.py:1129-1161); audio-seconds = the real clip lengths
-    gmix = torch.Generator().manual_seed(5)
-    secs = torch.randint(5, 31, (B,), generator=gmix)
-    secs[0] = 30
-    feat_len = ((secs * 16000 // 160 - 1) // 2 + 1).to(torch.int32).to(device)        # positions after conv2 (stride 2), <= 1500
-    enc.encode_btc(mel, feat_len=feat_len)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(3):
+    enc8, enc_mixed = None, None
+    if not args.no_extra_legs:
+        # BASELINE config 5 evidence (never the headline `value`): the same encoder batch with the four projections of every layer on
+        # e4m3 operands (afhip_gemm a_fp8: block-scaled MFMA, 2x the bf16 rate; activations quantised per row, LayerNorm fused)
+        ref_out = enc.encode_btc(mel)
+        enc.enable_fp8(True)
+        out8 = enc.encode_btc(mel)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(3):
+            enc.encode_btc(mel)
+        ev1.record()
+        torch.cuda.synchronize()
+        enc8_ms = ev0.elapsed_time(ev1) / 3
+        d8 = (out8.float() - ref_out.float()).abs()
+        enc8 = {"encoder_ms": enc8_ms, "encoder_audio_s_per_s": B * 30.0 / (enc8_ms * 1e-3), "speedup_vs_bf16": enc_ms / enc8_ms,
+                "vs_bf16_output_max_abs": float(d8.max()), "vs_bf16_output_mean_abs": float(d8.mean()),
+                "what": "e4m3 x e4m3 MFMA GEMMs for qkv / out / fc1 (per-row activation scales from a fused LayerNorm + quantise pass, per-channel weight scales, f32 accumulate); fc2, the residual stream and attention stay bf16"}
+        enc.enable_fp8(False)
+        del ref_out, out8, d8
+        # BASELINE config 2, second run: the same 32 clips with mixed 5-30 s lengths in the self-test convention
+        # (length = after-conv length -> key-padding mask per clip, audio.py:1129-1161); audio-seconds = the real clip lengths
+        gmix = torch.Generator().manual_seed(5)
+        secs = torch.randint(5, 31, (B,), generator=gmix)
+        secs[0] = 30
+        feat_len = ((secs * 16000 // 160 - 1) // 2 + 1).to(torch.int32).to(device)        # positions after conv2 (stride 2), <= 1500
         enc.encode_btc(mel, feat_len=feat_len)
-    ev1.record()
-    torch.cuda.synchronize()
-    mix_ms = ev0.elapsed_time(ev1) / 3
-    # ... and on packed rows (afhip_encoder_forward_ragged): the layers run on M = sum of lengths rows; the kept rows are bit-identical
-    enc.encode_btc(mel, feat_len=feat_len, ragged=True)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(3):
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(3):
+            enc.encode_btc(mel, feat_len=feat_len)
+        ev1.record()
+        torch.cuda.synchronize()
+        mix_ms = ev0.elapsed_time(ev1) / 3
+        # ... and on packed rows (afhip_encoder_forward_ragged): the layers run on M = sum of lengths rows; the kept rows are bit-identical
         enc.encode_btc(mel, feat_len=feat_len, ragged=True)
-    ev1.record()
-    torch.cuda.synchronize()
-    rag_ms = ev0.elapsed_time(ev1) / 3
-    enc_mixed = {"encoder_ms": rag_ms, "clip_seconds_total": int(secs.sum()), "encoder_audio_s_per_s": float(secs.sum()) / (rag_ms * 1e-3),
-                 "padded_encoder_ms": mix_ms, "padded_encoder_audio_s_per_s": float(secs.sum()) / (mix_ms * 1e-3),
-                 "what": "mixed 5-30 s clips, length = after-conv length (key-padding mask per clip). encoder_ms: layers on the packed valid positions "
-                         "(M = sum of lengths, what ContinuousAudioIO.encode_batch runs for ragged batches); padded_*: all 1500 positions of every "
-                         "clip as the reference computes them (dead key tiles skipped)"}
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(3):
+            enc.encode_btc(mel, feat_len=feat_len, ragged=True)
+        ev1.record()
+        torch.cuda.synchronize()
+        rag_ms = ev0.elapsed_time(ev1) / 3
+        enc_mixed = {"encoder_ms": rag_ms, "clip_seconds_total": int(secs.sum()), "encoder_audio_s_per_s": float(secs.sum()) / (rag_ms * 1e-3),
+                     "padded_encoder_ms": mix_ms, "padded_encoder_audio_s_per_s": float(secs.sum()) / (mix_ms * 1e-3),
+                     "what": "mixed 5-30 s clips, length = after-conv length (key-padding mask per clip). encoder_ms: layers on the packed valid positions "
+                             "(M = sum of lengths, what ContinuousAudioIO.encode_batch runs for ragged batches); padded_*: all 1500 positions of every "
+                             "clip as the reference computes them (dead key tiles skipped)"}
 
     res = None
     if rank == 0:
