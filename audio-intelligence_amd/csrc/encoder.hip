@@ -139,7 +139,8 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
     // stream.  out-proj / fc2 emit row (sum, sum of squares) partials of what they store, a 3-us finalize turns them into
     // (mean, rstd), and q/k/v / fc1 run on the RAW stream with gamma folded into their weights (afhip.h).
     const bool fold = dt == AFHIP_BF16 && w->qkv_wf && w->qkv_cs && w->qkv_bf && w->fc1_wf && w->fc1_cs && w->fc1_bf &&
-                      rows >= 512 && d % 256 == 0 && f % 256 == 0 && gemm_pp_available();
+                      B * Tp >= 512 && d % 256 == 0 && f % 256 == 0 && gemm_pp_available();      // decided on the PADDED row count: the packed
+                                                                                               // forward must take the same arithmetic
     const int P = d / 64;
     // e4m3-operand mode (BASELINE config 5): explicit LayerNorm fused into the per-row quantisation pass, four fp8 GEMMs per layer
     const bool f8 = dt == AFHIP_BF16 && w->qkv_w8 && w->qkv_s8 && w->out_w8 && w->out_s8 && w->fc1_w8 && w->fc1_s8 && w->fc2_w8 && w->fc2_s8 &&

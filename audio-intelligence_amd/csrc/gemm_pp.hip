@@ -587,7 +587,9 @@ bool gemm_pp_eligible(const afhip_gemm_args* a) {
     if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
     if (a->ln_stats && (a->act == AFHIP_ACT_SWIGLU || a->residual || a->row_stats_out || !a->ln_colsum || !a->ln_bias)) return false;
     if (a->row_stats_out && (a->act != AFHIP_ACT_NONE || !a->bias || !a->residual)) return false;
-    if (a->M < 512 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
+    // small M is a throughput heuristic only (the 128 x 128 kernel wastes less of a near-empty tile); the LayerNorm-folded forms
+    // exist only here, so they take any M (a packed ragged batch can be a few hundred rows)
+    if ((a->M < 512 && !a->ln_stats && !a->row_stats_out) || a->M < 1 || (a->N % PP_BN) != 0 || (a->K % (2 * PP_BK)) != 0) return false;
     if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
     if (a->bias && ((uintptr_t)a->bias % 16)) return false;
     if (a->residual && ((a->ldres % 8) || ((uintptr_t)a->residual % 16))) return false;

@@ -290,6 +290,10 @@ def test_ragged_packed_forward_full_shape_bf16_and_encode_batch():
         assert bool(torch.isfinite(ragged[b, :k].float()).all()), f"clip {b} (len {n}): non-finite rows"
         assert torch.equal(ragged[b, :k], padded[b, :k]), f"clip {b} (len {n}): kept rows differ"
         assert bool((ragged[b, k:] == 0).all())
+    # a packed batch of a few hundred rows keeps the LayerNorm-folded arithmetic of the padded forward (one clip of 5 s)
+    one = torch.tensor([250], dtype=torch.int32)
+    r1, p1 = enc.encode_btc(mel[:1], feat_len=one, ragged=True), enc.encode_btc(mel[:1], feat_len=one)
+    assert torch.equal(r1[0, :125], p1[0, :125]) and bool((r1[0, 125:] == 0).all())
     io = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="bfloat16", device=DEV, encoder=enc)
     length = torch.tensor([750, 167, 500, 32, 600, 250])           # encode_batch: L = 4 length - 1 mel frames -> feat_len = 2 length
     outs = io.encode_batch(mel, length)
