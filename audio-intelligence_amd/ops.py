@@ -206,6 +206,32 @@ def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Te
     return out
 
 
+def attention_ragged(qkv_rows: torch.Tensor, n_heads: int, lengths: torch.Tensor, max_len: int):
+    """Self-attention on PACKED fused rows qkv [sum(lengths), 3*d]: sequence b owns rows [off_b, off_b + lengths[b]) with
+    off = exclusive cumsum(lengths) (afhip_attn_args.row_off) -> [sum(lengths), d]."""
+    lib = L.lib()
+    _chk(qkv_rows, "attention.qkv")
+    R, D3 = qkv_rows.shape
+    d = D3 // 3
+    hd = d // n_heads
+    assert qkv_rows.is_contiguous() and int(lengths.sum()) == R and int(lengths.max()) <= max_len
+    key_len = lengths.to(device=qkv_rows.device, dtype=torch.int32).contiguous()
+    row_off = (torch.cumsum(key_len, 0, dtype=torch.int32) - key_len).contiguous()
+    out = torch.empty((R, d), dtype=qkv_rows.dtype, device=qkv_rows.device)
+    sz = qkv_rows.element_size()
+    a = L.AttnArgs()
+    a.q, a.k, a.v = qkv_rows.data_ptr(), qkv_rows.data_ptr() + d * sz, qkv_rows.data_ptr() + 2 * d * sz
+    a.out = out.data_ptr()
+    a.key_len, a.row_off = key_len.data_ptr(), row_off.data_ptr()
+    a.B, a.Tq, a.Tk, a.n_q, a.n_kv, a.hd = key_len.numel(), max_len, max_len, n_heads, n_heads, hd
+    a.ld_q = a.ld_kv = D3
+    a.ld_o = d
+    a.q_head_stride = a.kv_head_stride = hd
+    a.causal, a.q_pos0, a.scale, a.dtype = 0, 0, 1.0 / math.sqrt(hd), L.dtype_code(qkv_rows.dtype)
+    L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
+    return out
+
+
 def attention_cache(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int, tk: int,
                     q_pos0: int, ld_q: Optional[int] = None):
     """Causal GQA attention of q rows [B,Tq,(>=)n_q*hd] against a KV cache [B,n_kv,cap,hd] holding tk valid keys."""

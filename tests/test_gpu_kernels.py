@@ -620,3 +620,38 @@ def test_torch_library_ops_dispatch_to_the_hip_library():
     wav = (_rand(2, 480000, seed=45) * 0.1).to(_dev())
     mel = torch.ops.afhip.log_mel(wav, True, torch.float32)
     assert tuple(mel.shape) == (2, 3000, 128)
+
+
+@pytest.mark.parametrize("dt,hd,tol", [(torch.float32, 64, 2e-5), (torch.bfloat16, 64, 2e-2), (torch.bfloat16, 128, 2e-2)])
+def test_attention_packed_ragged_rows(dt, hd, tol):
+    """afhip_attn_args.row_off: sequences of different lengths packed back to back (rows of the NEXT sequence sit right behind a
+    sequence's last key, NaNs behind the last one) against per-sequence fp32 softmax attention on the same rounded operands, and
+    bit-identical to the [B, T] form with key lengths."""
+    DEV = _dev()
+    from audio_intelligence_amd import ops
+    nh = 3
+    d = nh * hd
+    lens = torch.tensor([200, 1, 64, 333, 129, 0, 65])
+    g = torch.Generator().manual_seed(17)
+    R = int(lens.sum())
+    buf = torch.full((R + 130, 3 * d), float("nan"))                        # 130 poisoned rows behind the last sequence
+    buf[:R] = torch.randn(R, 3 * d, generator=g) * 1.2
+    buf = buf.to(dt)
+    out = ops.attention_ragged(buf.to(DEV)[:R], nh, lens, 384).float().cpu()
+    assert bool(torch.isfinite(out).all())
+    off = 0
+    padded = torch.zeros(len(lens), 384, 3 * d, dtype=dt)
+    for b, n in enumerate(lens.tolist()):
+        x = buf[off:off + n].float()
+        if n:
+            q, k, v = (x[:, i * d:(i + 1) * d].view(n, nh, hd).transpose(0, 1) for i in range(3))
+            ref = torch.matmul(torch.softmax(torch.matmul(q, k.transpose(1, 2)) / np.sqrt(hd), -1), v).transpose(0, 1).reshape(n, d)
+            err = float((out[off:off + n] - ref).abs().max())
+            assert err <= tol, (b, n, err)
+            padded[b, :n] = buf[off:off + n]
+        off += n
+    ref_bt = ops.attention_packed(padded.to(DEV), nh, key_len=lens.to(torch.int32).to(DEV)).cpu()
+    off = 0
+    for b, n in enumerate(lens.tolist()):
+        assert torch.equal(ref_bt[b, :n].float(), out[off:off + n]), f"sequence {b}: packed rows differ from the [B, T] form"
+        off += n
