@@ -345,6 +345,128 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyP p) {
     }
 }
 
+// ---- persistent form of the SwiGLU pair GEMM (decode gate/up: bf16, M <= 16) --------------------------------------------------
+// One workgroup per CU walks its pair units (TR gate rows + their up rows each) in ONE continuous weight stream: the per-wave
+// window of DEPTH K steps rolls across unit boundaries, so the first loads of the next unit are in flight while the K slices of
+// the finished unit are combined; the activations (RMSNorm gain applied, row sums of squares taken) are staged in LDS once per
+// workgroup, not once per unit, so the stream issues weight loads only.  The plain form above starts 1263 workgroups of 7 K
+// steps per wave: every one of them pays an HBM round trip before its first MFMA and re-reads its activation fragments from L2.
+// A row's K order and the order of the K-slice sum are those of skinny_kernel: same bits.
+template <int AMODE, int DEPTH>
+__global__ __launch_bounds__(512) void skinny_pair_persist_kernel(SkinnyP p) {
+    constexpr int NW = 8, KS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                 // [2 unit parities][8 waves][2 tiles][64 lanes][4]
+    float* red_ss = red + 2 * NW * 2 * 256;                       // [16] row sums of squares (A_RMSNORM)
+    char* aimg = reinterpret_cast<char*>(red_ss + 16);            // [K / 64][2 halves][4 q][a_rows] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int TR = p.tile_rows, gates = p.N >> 1, RM = p.a_rows;
+    const int n_units = (gates + TR - 1) / TR;
+    const int spw = p.K / (KS * NW);                              // K steps per wave per unit (the host checks K % 512 == 0)
+    const int my_units = (n_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_units * spw;                             // this wave's steps over all its units, in stream order
+    const int cr = c16 < TR ? c16 : TR - 1;
+
+    // ---- issue side: which unit / step the stream is at ----
+    const char* wrow0 = nullptr;
+    const char* wrow1 = nullptr;
+    auto set_rows = [&](int ui) {
+        int g = ((int)blockIdx.x + ui * (int)gridDim.x) * TR + cr;
+        g = g < gates ? g : gates - 1;
+        const long long n = ((long long)(g >> 5) << 6) + (g & 31);      // gate g = W row 64 (g >> 5) + (g & 31), its up row 32 further
+        wrow0 = p.W + n * p.ldw * 2;
+        wrow1 = wrow0 + 32 * p.ldw * 2;
+    };
+    struct Regs { u32x4 g0, g1, u0, u1; };
+    Regs r[DEPTH];
+    int ig = 0, iu = 0, ij = 0;                                    // next step to issue: stream index, unit, step inside the unit
+    auto issue = [&](Regs& x) {
+        const long long koff = (long long)(wave + NW * ij) * (KS * 2) + q * 32;
+        x.g0 = ld16(wrow0 + koff); x.g1 = ld16(wrow0 + koff + 16);
+        x.u0 = ld16(wrow1 + koff); x.u1 = ld16(wrow1 + koff + 16);
+        ++ig;
+        if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
+    };
+    set_rows(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (ig < total) issue(r[d]);
+
+    // ---- activations -> LDS, once (same image and arithmetic as skinny_kernel's ALDS form) ----
+    for (int m = wave; m < RM; m += NW) {
+        const bool real = m < p.M;
+        const char* src = p.A + (long long)m * p.lda * 2;
+        float sq = 0.f;
+        for (int cc = lane; cc < p.K / 8; cc += 64) {
+            u32x4 v = real ? ld16(src + cc * 16) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (AMODE == A_RMSNORM) {
+                const u32x4 g = ld16(p.norm_w + cc * 16);
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = elem<bf16>(v, e);
+                    sq += x * x;
+                    f[e] = x * elem<bf16>(g, e);
+                }
+                v = pack<bf16>(f);
+            }
+            st16(aimg + (cc >> 3) * (RM * 128) + (cc & 1) * (RM * 64) + ((((cc >> 1) & 3) * RM + m) << 4), v);
+        }
+        if constexpr (AMODE == A_RMSNORM) {
+            sq = wave_sum(sq);
+            if (lane == 0) red_ss[m] = sq;
+        }
+    }
+    __syncthreads();
+    const int a_lane = (q * RM + (c16 & (RM - 1))) << 4;
+
+    f32x4 accg = f32x4{0.f, 0.f, 0.f, 0.f}, accu = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cu = 0, cj = 0;                                            // consume side: unit, step inside the unit
+    auto finish_unit = [&]() {
+        float* rp = red + (cu & 1) * (NW * 2 * 256);              // two buffers: the next unit's barrier orders the reuse
+        *reinterpret_cast<f32x4*>(rp + (((wave * 2 + 0) * 64 + lane) << 2)) = accg;
+        *reinterpret_cast<f32x4*>(rp + (((wave * 2 + 1) * 64 + lane) << 2)) = accu;
+        accg = f32x4{0.f, 0.f, 0.f, 0.f}; accu = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (tid < 256) {
+            const int reg = tid & 3, ln = tid >> 2;
+            float g = 0.f, u = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                g += rp[(((w * 2 + 0) * 64 + ln) << 2) + reg];
+                u += rp[(((w * 2 + 1) * 64 + ln) << 2) + reg];
+            }
+            const int mrow = 4 * (ln >> 4) + reg;
+            const int gi = ((int)blockIdx.x + cu * (int)gridDim.x) * TR + (ln & 15);
+            if ((ln & 15) < TR && gi < gates && mrow < p.M) {
+                if constexpr (AMODE == A_RMSNORM) {
+                    const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.norm_eps);
+                    g *= rs; u *= rs;
+                }
+                reinterpret_cast<bf16*>(p.C)[(long long)mrow * p.ldc + gi] = (bf16)(silu(g) * u);
+            }
+        }
+    };
+    for (int g0 = 0; g0 < total; g0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g0 + d < total) {                                  // workgroup-uniform: every wave has the same step count
+                const int s = wave + NW * cj;
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 128) + a_lane);
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 128) + RM * 64 + a_lane);
+                accg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, r[d].g0), accg, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, r[d].g1), accg, 0, 0, 0);
+                accu = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, r[d].u0), accu, 0, 0, 0);
+                accu = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, r[d].u1), accu, 0, 0, 0);
+                if (ig < total) issue(r[d]);
+                if (++cj == spw) { finish_unit(); cj = 0; ++cu; }
+            }
+        }
+    }
+}
+
+
 // NW = waves that split K inside a workgroup.  The narrow bf16 tiles (NT = 1: q/k/v and o of the decoder, 224-288 workgroups of
 // 7 K steps per wave) can split K over 16 waves (SKINNY_NW1); f32 always keeps 8 (its summation order is part of
 // the bit-exact parity contract).
@@ -447,6 +569,26 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
         nt_narrow = rpw <= 16 ? 1 : 2;
         p.tile_rows = rpw <= 16 ? rpw : (rpw <= 32 ? cdiv(rpw, 2) : 16);
         if (mt > 2 && nt_narrow == 2) { nt_narrow = 1; p.tile_rows = 16; }      // LDS of the K-slice combine: NT * MT <= 4 tiles
+    }
+    if (a->dtype == AFHIP_BF16 && sw_out && mt == 1 && amode != A_SWIGLU && a->K % 512 == 0) {
+        // decode gate/up: the persistent pair form (one continuous weight stream per CU); AFHIP_SKINNY_PERSIST=0 keeps the plain form
+        static int persist = -1;
+        if (persist < 0) { const char* e = getenv("AFHIP_SKINNY_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+        const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
+        if (persist && lds <= 150 * 1024) {
+            constexpr int PD = 4;      // K steps in flight per wave; 6 and 8 measured the same (3.47-3.52 ms per 7B step): not the limiter
+            static unsigned long long attr_done = 0;
+            if (afhip_first_use_on_device(&attr_done)) {
+                (void)hipFuncSetAttribute((const void*)skinny_pair_persist_kernel<A_RMSNORM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute((const void*)skinny_pair_persist_kernel<A_PLAIN, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            }
+            const int units = cdiv(a->N / 2, p.tile_rows), cus = afhip_cu_count();
+            const dim3 grid((unsigned)(units < cus ? units : cus)), block(512);
+            if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_pair_persist_kernel<A_RMSNORM, PD>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((skinny_pair_persist_kernel<A_PLAIN, PD>), grid, block, lds, s, p);
+            AFHIP_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (a->dtype == AFHIP_BF16) {
         if (sw_out) launch_mt<bf16, 2>(p, mt, amode, s);
