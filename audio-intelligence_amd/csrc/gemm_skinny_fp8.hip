@@ -298,6 +298,139 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(SkinnyF8P p) {
     }
 }
 
+// ---- persistent form of the SwiGLU pair GEMM with e4m3 weights (decode gate/up, M <= 16): see skinny_pair_persist_kernel in
+// gemm_skinny.hip.  A K step is 128 deep here, so K = 3584 gives the eight waves 4 or 3 steps per unit: every wave walks its own
+// step count per unit and all of them meet at the unit's combine barrier.  Same K order per row, same K-slice sum order: same bits.
+template <int AMODE, int DEPTH>
+__global__ __launch_bounds__(512) void skinny_fp8_pair_persist_kernel(SkinnyF8P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                 // [2 unit parities][8 waves][2 tiles][64 lanes][4]
+    float* red_ss = red + 2 * 8 * 2 * 256;                        // [16]
+    char* aimg = reinterpret_cast<char*>(red_ss + 16);            // [K / 128][4][4][a_rows] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int TR = p.tile_rows, gates = p.N >> 1, RM = p.a_rows;
+    const int n_units = (gates + TR - 1) / TR;
+    const int nsteps = p.K / KS8;
+    const int spw = (nsteps - wave + 7) / 8;                      // this wave's K steps per unit (>= 1: the host checks K >= 1024)
+    const int my_units = (n_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_units * spw;
+    const int cr = c16 < TR ? c16 : TR - 1;
+    const char* wrow0 = nullptr;
+    const char* wrow1 = nullptr;
+    auto set_rows = [&](int ui) {
+        int g = ((int)blockIdx.x + ui * (int)gridDim.x) * TR + cr;
+        g = g < gates ? g : gates - 1;
+        const long long n = ((long long)(g >> 5) << 6) + (g & 31);
+        wrow0 = p.W + n * p.ldw;
+        wrow1 = wrow0 + 32 * p.ldw;
+    };
+    struct Regs { u32x4 g[2], u[2]; };
+    Regs r[DEPTH];
+    int ig = 0, iu = 0, ij = 0;
+    auto issue = [&](Regs& x) {
+        const long long k0 = (long long)(wave + 8 * ij) * KS8 + q * 32;
+        x.g[0] = ld16(wrow0 + k0); x.g[1] = ld16(wrow0 + k0 + 16);
+        x.u[0] = ld16(wrow1 + k0); x.u[1] = ld16(wrow1 + k0 + 16);
+        ++ig;
+        if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
+    };
+    set_rows(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (ig < total) issue(r[d]);
+    // activations -> LDS once (image and arithmetic of skinny_fp8_kernel's ALDS form)
+    for (int m = wave; m < RM; m += 8) {
+        const bool real = m < p.M;
+        const char* src = p.A + (long long)m * p.lda * 2;
+        float sq = 0.f;
+        for (int cc = lane; cc < p.K / 8; cc += 64) {
+            u32x4 v = real ? ld16(src + cc * 16) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (AMODE == A_RMSNORM) {
+                const u32x4 g = ld16(p.norm_w + cc * 16);
+                u32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float x0 = bf16_lo(v[d]), x1 = bf16_hi(v[d]);
+                    sq += x0 * x0 + x1 * x1;
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    bf16x2_t pr;
+                    pr[0] = (bf16)(x0 * bf16_lo(g[d]));
+                    pr[1] = (bf16)(x1 * bf16_hi(g[d]));
+                    o[d] = __builtin_bit_cast(uint32_t, pr);
+                }
+                v = o;
+            }
+            st16(aimg + (cc >> 4) * (RM * 256) + (cc & 3) * (RM * 64) + ((((cc >> 2) & 3) * RM + m) << 4), v);
+        }
+        if constexpr (AMODE == A_RMSNORM) {
+            sq = wave_sum(sq);
+            if (lane == 0) red_ss[m] = sq;
+        }
+    }
+    __syncthreads();
+    const int a_lane = (q * RM + (c16 & (RM - 1))) << 4;
+    f32x4 accg = f32x4{0.f, 0.f, 0.f, 0.f}, accu = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cu = 0, cj = 0;
+    auto widen = [&](const u32x4 (&w)[2], u32x4 (&wb)[4]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t lo, hi;
+                fp8x4_to_bf16x4(w[h][d], lo, hi);
+                wb[2 * h + (d >> 1)][2 * (d & 1)] = lo;
+                wb[2 * h + (d >> 1)][2 * (d & 1) + 1] = hi;
+            }
+    };
+    auto finish_unit = [&]() {
+        float* rp = red + (cu & 1) * (8 * 2 * 256);
+        *reinterpret_cast<f32x4*>(rp + (((wave * 2 + 0) * 64 + lane) << 2)) = accg;
+        *reinterpret_cast<f32x4*>(rp + (((wave * 2 + 1) * 64 + lane) << 2)) = accu;
+        accg = f32x4{0.f, 0.f, 0.f, 0.f}; accu = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (tid < 256) {
+            const int reg = tid & 3, ln = tid >> 2;
+            float g = 0.f, u = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                g += rp[(((w * 2 + 0) * 64 + ln) << 2) + reg];
+                u += rp[(((w * 2 + 1) * 64 + ln) << 2) + reg];
+            }
+            const int mrow = 4 * (ln >> 4) + reg;
+            const int gi = ((int)blockIdx.x + cu * (int)gridDim.x) * TR + (ln & 15);
+            if ((ln & 15) < TR && gi < gates && mrow < p.M) {
+                const int ng = ((gi >> 5) << 6) + (gi & 31);
+                float rs = 1.0f;
+                if constexpr (AMODE == A_RMSNORM) rs = rsqrtf(red_ss[mrow] / (float)p.K + p.norm_eps);
+                g *= rs * p.wscale[ng];
+                u *= rs * p.wscale[ng + 32];
+                reinterpret_cast<bf16*>(p.C)[(long long)mrow * p.ldc + gi] = (bf16)(silu(g) * u);
+            }
+        }
+    };
+    for (int g0 = 0; g0 < total; g0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g0 + d < total) {                                  // wave-uniform; every wave reaches each unit's barrier exactly once
+                const int s = wave + 8 * cj;
+                u32x4 a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const u32x4*>(aimg + s * (RM * 256) + c * (RM * 64) + a_lane);
+                u32x4 wb[4];
+                widen(r[d].g, wb);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) accg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[c]), __builtin_bit_cast(bf16x8, wb[c]), accg, 0, 0, 0);
+                widen(r[d].u, wb);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) accu = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[c]), __builtin_bit_cast(bf16x8, wb[c]), accu, 0, 0, 0);
+                if (ig < total) issue(r[d]);
+                if (++cj == spw) { finish_unit(); cj = 0; ++cu; }
+            }
+        }
+    }
+}
+
 template <int NT, int MT>
 void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
     const dim3 grid((NT == 2 && p.swiglu_out) ? (unsigned)cdiv(p.N / 2, p.tile_rows) : (unsigned)cdiv(p.N, NT * p.tile_rows)), block(512);
@@ -369,6 +502,26 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
         const int rpw = cdiv(a->N, afhip_cu_count());
         nt_narrow = rpw <= 16 ? 1 : 2;
         p.tile_rows = rpw <= 16 ? rpw : (rpw <= 32 ? cdiv(rpw, 2) : 16);
+    }
+    if (sw_out && mt == 1 && a->K >= 1024) {
+        // decode gate/up: persistent pair form (gemm_skinny.hip); AFHIP_SKINNY_PERSIST=0 keeps the plain form
+        static int persist = -1;
+        if (persist < 0) { const char* e = getenv("AFHIP_SKINNY_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+        const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
+        if (persist && lds <= 150 * 1024) {
+            constexpr int PD = 4;
+            static unsigned long long attr_done = 0;
+            if (afhip_first_use_on_device(&attr_done)) {
+                (void)hipFuncSetAttribute((const void*)skinny_fp8_pair_persist_kernel<A_RMSNORM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute((const void*)skinny_fp8_pair_persist_kernel<A_PLAIN, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            }
+            const int units = cdiv(a->N / 2, p.tile_rows), cus = afhip_cu_count();
+            const dim3 grid((unsigned)(units < cus ? units : cus)), block(512);
+            if (amode == A_RMSNORM) hipLaunchKernelGGL((skinny_fp8_pair_persist_kernel<A_RMSNORM, PD>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((skinny_fp8_pair_persist_kernel<A_PLAIN, PD>), grid, block, lds, s, p);
+            AFHIP_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (sw_out) launch_mt8<2>(p, mt, amode, s);
     else if (wide) launch_mt8<4>(p, mt, amode, s);
