@@ -572,8 +572,8 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     }
     if (a->dtype == AFHIP_BF16 && sw_out && mt == 1 && amode != A_SWIGLU && a->K % 512 == 0) {
         // decode gate/up: the persistent pair form (one continuous weight stream per CU); AFHIP_SKINNY_PERSIST=0 keeps the plain form
-        static int persist = -1;
-        if (persist < 0) { const char* e = getenv("AFHIP_SKINNY_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+        const char* pe = getenv("AFHIP_SKINNY_PERSIST");      // A/B switch, read per call so one process can compare the two forms
+        const int persist = (pe && pe[0] == '0') ? 0 : 1;
         const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
         if (persist && lds <= 150 * 1024) {
             constexpr int PD = 4;      // K steps in flight per wave; 6 and 8 measured the same (3.47-3.52 ms per 7B step): not the limiter

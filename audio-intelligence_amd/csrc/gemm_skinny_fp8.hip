@@ -505,8 +505,8 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     }
     if (sw_out && mt == 1 && a->K >= 1024) {
         // decode gate/up: persistent pair form (gemm_skinny.hip); AFHIP_SKINNY_PERSIST=0 keeps the plain form
-        static int persist = -1;
-        if (persist < 0) { const char* e = getenv("AFHIP_SKINNY_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+        const char* pe = getenv("AFHIP_SKINNY_PERSIST");      // A/B switch, read per call so one process can compare the two forms
+        const int persist = (pe && pe[0] == '0') ? 0 : 1;
         const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
         if (persist && lds <= 150 * 1024) {
             constexpr int PD = 4;

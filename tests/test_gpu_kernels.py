@@ -655,3 +655,52 @@ def test_attention_packed_ragged_rows(dt, hd, tol):
     for b, n in enumerate(lens.tolist()):
         assert torch.equal(ref_bt[b, :n].float(), out[off:off + n]), f"sequence {b}: packed rows differ from the [B, T] form"
         off += n
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,H,I", [(8, 3584, 4736), (1, 1024, 4096), (12, 1024, 5024), (16, 512, 4128)])
+def test_gemm_skinny_swiglu_persistent_form_keeps_the_plain_forms_bits(fp8, M, H, I):
+    """The persistent gate/up GEMM (one continuous weight stream per CU, activations staged once; bf16 and e4m3 weights) against
+    the plain one-workgroup-per-unit form (AFHIP_SKINNY_PERSIST=0) on the same operands: bit-identical (same K order per row, same
+    K-slice sum order), and against the fp32 reference.  Shapes: 7B hidden width, unit counts that are not multiples of the CU
+    count, gate counts that are not multiples of the tile rows, 8- and 16-row activation images."""
+    import ctypes as C
+    import os
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    dt = torch.bfloat16
+    xd, xf = _q(_rand(M, H, seed=91) * 2.0, dt)
+    gd, gf = _q(1 + 0.1 * _rand(H, seed=92), dt)
+    gate = _rand(I, H, seed=93, scale=0.05).to(dt)
+    up = _rand(I, H, seed=94, scale=0.05).to(dt)
+    packed = torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
+    wf = packed.float()
+    g = L.GemmArgs()
+    keep = []
+    if fp8:
+        from audio_intelligence_amd.utils.quant import quantize_rows_e4m3
+        q8, sc = quantize_rows_e4m3(packed.to(_dev()))
+        keep += [q8, sc]
+        wf = q8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]
+        g.W, g.w_scale = q8.data_ptr(), sc.data_ptr()
+    else:
+        wdev = packed.to(_dev())
+        keep.append(wdev)
+        g.W = wdev.data_ptr()
+    outs = []
+    for persist in ("1", "0"):
+        os.environ["AFHIP_SKINNY_PERSIST"] = persist
+        out = torch.full((M, I), float("nan"), dtype=dt, device=_dev())
+        g.A, g.C = xd.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, 2 * I, H, H, H, I
+        g.dtype, g.act, g.a_norm_w, g.a_norm_eps = L.dtype_code(dt), L.ACT_SWIGLU, gd.data_ptr(), 1e-6
+        L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+        outs.append(out.cpu())
+    os.environ.pop("AFHIP_SKINNY_PERSIST")
+    assert torch.equal(outs[0], outs[1]), "persistent and plain forms differ"
+    var = xf.pow(2).mean(-1, keepdim=True)
+    h = (gf * (xf * torch.rsqrt(var + 1e-6))).to(dt).float() if fp8 else gf * (xf * torch.rsqrt(var + 1e-6))
+    gw = wf.view(I // 32, 2, 32, H)
+    ref = F.silu(h @ gw[:, 0].reshape(I, H).T) * (h @ gw[:, 1].reshape(I, H).T)
+    # silu(g) * u: an error of 2^-9 |g| in one factor is multiplied by the other, so the absolute budget scales with the output range
+    _check(outs[0], ref, 4e-2 + 4e-3 * float(ref.abs().max()), 3e-2, f"persistent swiglu fp8={fp8} M={M} H={H} I={I}")
