@@ -84,7 +84,8 @@ class DecodeState(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("cfg_logits", C.c_void_p), ("cfg", C.c_float), ("rows", C.c_int), ("ld", C.c_int),
                 ("allowed", C.c_void_p), ("n_iv", C.c_int), ("k", C.c_int), ("temperature", C.c_float), ("model_dtype", C.c_int),
-                ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p), ("topk_prob", C.c_void_p), ("u", C.c_void_p), ("token", C.c_void_p)]
+                ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p), ("topk_prob", C.c_void_p), ("u", C.c_void_p), ("token", C.c_void_p),
+                ("one_minus_cfg", C.c_float)]
 
 
 # name -> (restype, argtypes); mirrors include/afhip.h one to one (tests/test_cabi.py checks the header against this)

@@ -177,13 +177,14 @@ __global__ void decode_update_kernel(const int64_t* __restrict__ tok, int64_t* _
                                      int32_t* __restrict__ finished_at, int B, int step, int eos, int eot,
                                      int32_t* __restrict__ seq_pos, int32_t* __restrict__ step_counter) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     if (step_counter) step = step_counter[0];          // every thread reads it before thread 0 of this (single) block bumps it
-    const int64_t t = tok[b];
-    out_tokens[(long long)step * B + b] = t;
-    prev[b] = t;
-    if ((t == eos || t == eot) && finished_at[b] < 0) finished_at[b] = step;
-    if (seq_pos) seq_pos[b] += 1;
+    if (b < B) {                                       // no early return: every thread of the block reaches the barrier below
+        const int64_t t = tok[b];
+        out_tokens[(long long)step * B + b] = t;
+        prev[b] = t;
+        if ((t == eos || t == eot) && finished_at[b] < 0) finished_at[b] = step;
+        if (seq_pos) seq_pos[b] += 1;
+    }
     __syncthreads();
     if (step_counter && b == 0) step_counter[0] = step + 1;
 }

@@ -125,7 +125,7 @@ extern "C" int afhip_sample_topk(const afhip_sample_args* a, void* stream) {
     AFHIP_CHECK(a->model_dtype == AFHIP_F32 || a->model_dtype == AFHIP_BF16, "afhip_sample_topk: bad model_dtype");
     AFHIP_CHECK(a->token == nullptr || a->u != nullptr, "afhip_sample_topk: token output needs the uniforms u");
     SampleP p;
-    p.logits = a->logits; p.cfg_logits = a->cfg_logits; p.cfg = a->cfg; p.one_minus_cfg = 1.0f - a->cfg;
+    p.logits = a->logits; p.cfg_logits = a->cfg_logits; p.cfg = a->cfg; p.one_minus_cfg = a->one_minus_cfg != 0.f ? a->one_minus_cfg : (float)(1.0 - (double)a->cfg);
     p.rows = a->rows; p.ld = a->ld; p.allowed = a->allowed; p.n_iv = a->n_iv; p.k = a->k; p.temperature = a->temperature;
     p.round_bf16 = a->model_dtype == AFHIP_BF16;
     p.topk_idx = a->topk_idx; p.topk_val = a->topk_val; p.topk_prob = a->topk_prob; p.u = a->u; p.token = a->token;

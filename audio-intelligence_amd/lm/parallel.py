@@ -480,6 +480,8 @@ class ParallelLLM(nn.Module):
         lib = L.lib()
         n, V = logits_f32.shape
         dev = logits_f32.device
+        if not 1 <= int(topk) <= 64:
+            raise ValueError(f"topk={topk}: afhip_sample_topk selects at most 64 candidates per row (the reference accepts any k; conf/inference.yaml uses 20)")
         idx = torch.empty((n, topk), dtype=torch.int32, device=dev)
         val = torch.empty((n, topk), dtype=torch.float32, device=dev)
         prob = torch.empty((n, topk), dtype=torch.float32, device=dev)
@@ -488,6 +490,7 @@ class ParallelLLM(nn.Module):
         a.logits, a.cfg_logits, a.cfg = logits_f32.data_ptr(), (cfg_logits.data_ptr() if cfg_logits is not None else None), float(cfg)
         a.rows, a.ld, a.allowed, a.n_iv, a.k = n, logits_f32.stride(0), allowed.data_ptr(), allowed.shape[1], int(topk)
         a.temperature = float(temperature)
+        a.one_minus_cfg = float(1.0 - cfg)               # Python double, rounded to f32 once -- as the reference's `(1 - cfg)` operand is (:489-492)
         a.model_dtype = L.dtype_code(model_dtype if model_dtype is not None else self.dtype)
         a.topk_idx, a.topk_val, a.topk_prob = idx.data_ptr(), val.data_ptr(), prob.data_ptr()
         a.u, a.token = (u.data_ptr() if u is not None else None), (tok.data_ptr() if tok is not None else None)
@@ -524,6 +527,7 @@ class ParallelLLM(nn.Module):
             dst[:, :B, :, :length] = a[:, :, :, :length]
             dst[:, B:, :, :length] = b[:, :, :, :length]
         both.length = length
+        del cfg_cache                                          # the unconditional half now lives in `both`
         return both
 
     @torch.no_grad()
@@ -555,15 +559,24 @@ class ParallelLLM(nn.Module):
         def one_step():
             L.check(lib.afhip_llm_decode_step(C.byref(pk.w), C.byref(cs), C.byref(st), B, max_pos, 0, L.ptr(ws), ws.numel(), L.stream_ptr()))
 
-        use_graph = os.environ.get("AFHIP_DECODE_GRAPH", "1") != "0" and max_step >= 4
+        # a capture costs a device synchronise + allocator housekeeping (~ms): only worth it for loops long enough to amortise it
+        use_graph = os.environ.get("AFHIP_DECODE_GRAPH", "1") != "0" and max_step >= 16 and not torch.cuda.is_current_stream_capturing()
         graph = None
         n_done = max_step
         for step in range(max_step):
+            captured_now = False
             if use_graph and step == 1:
-                # step 0 ran eagerly (first-use set-up of the kernels happens outside the capture); capture step 1 once, replay it
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    one_step()
+                # step 0 ran eagerly (first-use set-up of the kernels happens outside the capture); capture step 1 once, replay it.
+                # Capture does not execute, so when it fails (an outer capture, another thread issuing HIP calls under the global
+                # capture mode, ...) nothing of this step has happened yet: fall back to eager launches for the rest of the loop.
+                try:
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_):
+                        one_step()
+                    graph = g_
+                except Exception as e:  # noqa: BLE001 -- any capture failure means "no graph", never "no decode"
+                    graph, use_graph = None, False
+                    self._graph_fallback = repr(e)
             if graph is not None:
                 graph.replay()
             else:
@@ -625,6 +638,9 @@ class ParallelLLM(nn.Module):
             # guidance mix, the modality mask (as per-stream id intervals), top-k, softmax(/T) and the draw.
             lib = L.lib()
             nb = cache.batch                                   # num_hypo
+            # capacity for the whole segment up front (as the greedy loop does): growing 64 positions at a time would re-copy the
+            # cache O(n^2 / 64) times over an audio-output decode of thousands of steps
+            cache.reserve(cache.length + this_config["max_step"] + 2)
             if cfg > 1:
                 cache = self._prepare_cfg_cache(cache)
             S, V, H = self.num_stream, self.lm_head.weight.shape[0], self.cfg["hidden_size"]

@@ -35,15 +35,19 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def encode_windows_sharded(encode_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], windows: torch.Tensor,
                            n_valid: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
-                           out_spec: Optional[Tuple[int, int, torch.dtype]] = None, timing: Optional[dict] = None) -> torch.Tensor:
-    """windows [W, n<=480000] f32 waveform windows (identical on every rank), n_valid [W] valid sample counts.
+                           out_spec: Optional[Tuple[int, int, torch.dtype]] = None, timing: Optional[dict] = None,
+                           total_windows: Optional[int] = None) -> torch.Tensor:
+    """windows [W, n<=480000] f32 waveform windows, n_valid [W] valid sample counts.
     Each rank encodes its contiguous block with `encode_fn(wav_block, n_valid_block) -> [w_local, T, d]` and ONE
     all_gather_into_tensor returns the full [W, T, d] on every rank (window order preserved); there is no other collective and
-    no host synchronisation.  `out_spec` = (T, d, dtype) of one window's tokens -- static facts of the encoder (750, d_model,
-    model dtype) that a rank owning no window needs to size its send buffer; taken from `encode_fn.out_spec` when omitted
-    (make_tower_encode_fn sets it).  Works with world size 1 and without an initialised process group.
+    no host synchronisation.
+    `total_windows` = None: `windows` / `n_valid` hold ALL W windows on every rank (each rank slices its block out).
+    `total_windows` = W: they hold ONLY this rank's block [lo, hi) = shard_range(W, rank, world) -- each rank uploads its own
+    windows and nothing else (154 MB per rank stay on the host for config 4's 80 windows on 8 GPUs).
+    `out_spec` = (T, d, dtype) of one window's tokens -- static facts of the encoder (750, d_model, model dtype) that a rank owning
+    no window needs to size its send buffer; taken from `encode_fn.out_spec` when omitted (make_tower_encode_fn sets it).  Works
+    with world size 1 and without an initialised process group.
     `timing`: optional dict that receives HIP events around the collective (`gather_ev`) and its byte count (`gather_bytes`)."""
-    W = windows.shape[0]
     if not (dist.is_available() and dist.is_initialized()):
         return encode_fn(windows, n_valid)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -53,12 +57,17 @@ def encode_windows_sharded(encode_fn: Callable[[torch.Tensor, torch.Tensor], tor
     if spec is None:
         raise ValueError("encode_windows_sharded needs out_spec=(tokens_per_window, d_model, dtype) when run on more than one rank")
     T, D, dtype = spec
+    W = windows.shape[0] if total_windows is None else int(total_windows)
     lo, hi = shard_range(W, rank, world)
+    if total_windows is None:
+        windows, n_valid = windows[lo:hi], n_valid[lo:hi]
+    elif windows.shape[0] != hi - lo or n_valid.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} of {world} owns windows [{lo}, {hi}) of {W} but was handed {windows.shape[0]}")
     per = (W + world - 1) // world                      # padded block size so the gather is a single fixed-size call
     out = torch.empty((world * per, T, D), dtype=dtype, device=windows.device)
     buf = torch.empty((per, T, D), dtype=dtype, device=windows.device)
     if hi > lo:
-        local = encode_fn(windows[lo:hi], n_valid[lo:hi])
+        local = encode_fn(windows, n_valid)
         if tuple(local.shape[1:]) != (T, D) or local.dtype != dtype:
             raise ValueError(f"encode_fn returned {tuple(local.shape)} {local.dtype}, out_spec says [*, {T}, {D}] {dtype}")
         buf[: hi - lo].copy_(local)
@@ -128,7 +137,7 @@ def build_long_prompt(prompt_ids: Sequence[int], n_samples: int, text_offset: in
 def long_audio_inference(model, audio_io, clips: Sequence[np.ndarray], prompts: Sequence[Sequence[int]], inference_config: dict,
                          enforce_modality: Optional[str] = "text", group: Optional[dist.ProcessGroup] = None,
                          io_name: str = "continuous_audio", timing: Optional[dict] = None):
-    """Config 4 end to end on one node.  `clips`: 16 kHz mono waveforms of any length, identical on every rank; `prompts`: text
+    """Config 4 end to end on one node.  `clips`: 16 kHz mono waveforms of any length, the same list on every rank (host memory; each rank uploads only its own windows); `prompts`: text
     ids per clip.  Steps: (1) every clip is cut into 30-s windows and ALL windows of the batch are sharded over the ranks
     (window w of the flat list -> the rank whose contiguous block holds it); (2) log-mel + encoder on the local block;
     (3) one all-gather returns every window's [750, d] tokens to every rank; (4) clip c is owned by rank c % world: the owner
@@ -144,11 +153,13 @@ def long_audio_inference(model, audio_io, clips: Sequence[np.ndarray], prompts: 
         for a, b in split_windows(len(wav)):
             spans.append((c, a, b))
     W = len(spans)
-    wins = torch.zeros((W, WINDOW_SAMPLES), dtype=torch.float32)
-    for i, (c, a, b) in enumerate(spans):
+    lo, hi = shard_range(W, rank, world)                  # this rank cuts, pads and uploads ONLY its own block of windows
+    wins = torch.zeros((hi - lo, WINDOW_SAMPLES), dtype=torch.float32)
+    for i, (c, a, b) in enumerate(spans[lo:hi]):
         wins[i, : b - a] = torch.from_numpy(np.ascontiguousarray(clips[c][a:b], dtype=np.float32))
-    n_valid = torch.tensor([b - a for _, a, b in spans], dtype=torch.long)
-    tokens = encode_windows_sharded(make_tower_encode_fn(audio_io), wins.to(dev), n_valid.to(dev), group=group, timing=timing)
+    n_valid = torch.tensor([b - a for _, a, b in spans[lo:hi]], dtype=torch.long)
+    tokens = encode_windows_sharded(make_tower_encode_fn(audio_io), wins.to(dev), n_valid.to(dev), group=group, timing=timing,
+                                    total_windows=W)
     text_offset = model.vocab_intervals["text"][0][0]
     results = {}
     for c, wav in enumerate(clips):

@@ -4,28 +4,132 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Started as ONE process with --gpus N > 1 (no RANK / WORLD_SIZE in the environment) it launches its N ranks itself: N fresh
+child processes of this same script, one per GPU, started BEFORE anything touches the GPU (plain fork + exec of a process that
+has made no HIP call; never a re-exec of an initialised one), rendezvous on 127.0.0.1.
+
 Headline workload (BASELINE.json configs[1]): AF-Whisper encoder only -- log-mel + 32-layer encoder, batch = 32 clips
 of 30 s @ 16 kHz per GPU, bf16 storage / f32 accumulate, synthetic audio and seeded random weights of the true shape.
 One step = one pass of the hot path over one batch whose waveforms are already resident in HBM.  Clips are
 independent (the reference shards them `samples[rank::world_size]` with no communication, dataloader/dataset.py:80),
-so N GPUs = N replicas of the same per-GPU batch: weak scaling, no data-path collective.
+so N GPUs = N replicas of the same per-GPU batch: weak scaling, no data-path collective.  For N > 1 the line additionally
+carries a `long_audio` object: BASELINE configs[3]'s 80 windows sharded over the ranks with the ONE RCCL all-gather of audio
+tokens the path has, the collective timed with HIP events against the xGMI figure.
 
 Rank 0 prints ONE JSON line: the bench contract + `roofline` (dominant kernel = the bf16 MFMA GEMM, timed live with
 HIP events inside the timed region), `cpu_baseline` (the CPU oracle timed on this host, N=1 only), plus the log-mel
 kernel's HBM figure and an AF3-7B-shape greedy-decode leg (decode tokens/s, the second half of BASELINE's metric).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="30-s clips per GPU per step")
+    ap.add_argument("--no-decode", action="store_true", help="skip the AF3-7B decode leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp8 / mixed-length encoder legs (profiles: only the headline kernels run)")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the hipBLASLt comparator GEMMs")
+    ap.add_argument("--no-long-audio", action="store_true", help="N > 1: skip the long-audio (RCCL all-gather) leg")
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    ap.add_argument("--workload", choices=["encoder", "long_audio", "decode"], default="encoder",
+                    help="encoder = BASELINE configs[1] (the headline); long_audio = configs[3]: 4 x 10-min clips, windows sharded over the ranks, "
+                         "one RCCL all-gather; decode = ONLY the AF3-7B greedy decode loop (configs[2], B = 8, bf16), for kernel profiles")
+    ap.add_argument("--decode-steps", type=int, default=128)
+    ap.add_argument("--decode-batch", type=int, default=8)
+    ap.add_argument("--decode-fp8", action="store_true", help="--workload decode: W8A16 weights instead of bf16")
+    ap.add_argument("--selftest-rendezvous", action="store_true",
+                    help="launcher self-test (CPU, gloo): ranks rendezvous, barrier, reduce a fake elapsed time, gather one small tensor; no GPU work")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, extra_env=None, timeout=None):
+    """Start `n` fresh processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run sets
+    them), wait for all of them, return the worst exit code.  The caller has not touched the GPU: children are ordinary
+    fork + exec of an uninitialised parent.  If a rank dies the others are ended by PID (they would wait at a barrier for ever)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "AFHIP_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    t0 = time.time()
+    rc, alive = 0, list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or (code if code > 0 else 128 - code)
+                for q in alive:                                      # exact PIDs we started
+                    q.terminate()
+        if timeout is not None and time.time() - t0 > timeout:
+            for q in alive:
+                q.kill()
+            rc = rc or 124
+        time.sleep(0.05)
+    return rc
+
+
+def _selftest_rendezvous(args):
+    """What every multi-rank run does around its timed region, with no GPU: gloo rendezvous from the launcher's environment, barrier,
+    MAX-reduce of a per-rank elapsed time, one all_gather_into_tensor in window order."""
+    import torch  # noqa: E402
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    from audio_intelligence_amd.long_audio import encode_windows_sharded, shard_range
+    W = 2 * world + 1
+    lo, hi = shard_range(W, rank, world)
+    blk = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1)
+    out = encode_windows_sharded(lambda w, n: w.reshape(-1, 1, 1).expand(-1, 3, 2).contiguous(), blk, torch.ones(hi - lo), out_spec=(3, 2, torch.float32), total_windows=W)
+    ok = bool(torch.equal(out[:, 0, 0], torch.arange(W, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"selftest": "rendezvous", "n_gpus": world, "max_elapsed": float(t.item()), "gather_in_window_order": ok,
+                          "spawned_by_bench": os.environ.get("AFHIP_BENCH_SPAWNED") == "1"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok and float(t.item()) == float(world) else 1
+
+
+if __name__ == "__main__":
+    _args = parse_args()
+    if "WORLD_SIZE" not in os.environ and _args.gpus > 1:
+        sys.exit(spawn_ranks(_args.gpus, sys.argv[1:]))              # before `import torch` / the HIP library: nothing GPU-side exists yet
+    if _args.selftest_rendezvous:
+        sys.exit(_selftest_rendezvous(_args))
+
+import ctypes as C  # noqa: E402
+
+import torch
 
 from audio_intelligence_amd import _lib as L  # noqa: E402
 from audio_intelligence_amd.utils import synthetic as syn  # noqa: E402
@@ -287,25 +391,31 @@ def decode_leg(device, model, n_vocab, fe, B, n_steps, warm, config_name):
     return res
 
 
-def long_audio_workload(args, device, dist, rank, world, enc, fe):
-    """BASELINE configs[3]: 4 x 10-minute clips = 80 windows of 30 s, sharded over the ranks in contiguous blocks; each rank runs
-    log-mel + encoder on its block, ONE all_gather_into_tensor returns every window's [750, 1280] bf16 tokens to every rank
-    (timed on its own with HIP events, against the xGMI figure of SURVEY 8d); then, unless --no-decode, clip c's owner rank
-    (c % world) splices its 20 windows into one prompt, prefills ~15 000 positions at the AF3-7B shape and decodes 128 tokens."""
-    from audio_intelligence_amd.long_audio import encode_windows_sharded, make_tower_encode_fn, build_long_prompt
+def long_audio_workload(args, device, dist, rank, world, enc, fe, with_llm=True, steps=None, warmup=None):
+    """BASELINE configs[3]: 4 x 10-minute clips = 80 windows of 30 s, sharded over the ranks in contiguous blocks; each rank
+    generates / uploads ONLY its own block, runs log-mel + encoder on it, and ONE all_gather_into_tensor returns every window's
+    [750, 1280] bf16 tokens to every rank (timed on its own with HIP events, against the xGMI figure of SURVEY 8d); then, with
+    `with_llm`, clip c's owner rank (c % world) splices its 20 windows into one prompt, prefills ~15 000 positions at the AF3-7B
+    shape and decodes 128 tokens."""
+    from audio_intelligence_amd.long_audio import encode_windows_sharded, make_tower_encode_fn, build_long_prompt, shard_range
     from audio_intelligence_amd.multimodal_io.audio import ContinuousAudioIO
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     n_clips, win_per_clip = 4, 20
     W = n_clips * win_per_clip
     io = ContinuousAudioIO(encoder_choice="AFWhisper", dtype="bfloat16", device=str(device), encoder=enc)
-    g = torch.Generator(device=device).manual_seed(3000)
-    wins = torch.randn((W, 480000), generator=g, device=device) * 0.1          # identical on every rank (same seed)
-    n_valid = torch.full((W,), 480000, dtype=torch.long, device=device)
+    lo, hi = shard_range(W, rank, world)
+    wins = torch.empty((hi - lo, 480000), dtype=torch.float32, device=device)
+    for i, w in enumerate(range(lo, hi)):                     # window w has the same samples whatever the world size
+        g = torch.Generator(device=device).manual_seed(3000 + w)
+        wins[i] = torch.randn(480000, generator=g, device=device) * 0.1
+    n_valid = torch.full((hi - lo,), 480000, dtype=torch.long, device=device)
     fn = make_tower_encode_fn(io)
 
     def step(timing=None):
-        return encode_windows_sharded(fn, wins, n_valid, timing=timing)
+        return encode_windows_sharded(fn, wins, n_valid, timing=timing, total_windows=W)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tokens = step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -313,7 +423,7 @@ def long_audio_workload(args, device, dist, rank, world, enc, fe):
     torch.cuda.synchronize()
     gathers = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         tm = {}
         tokens = step(tm)
         gathers.append(tm)
@@ -324,23 +434,29 @@ def long_audio_workload(args, device, dist, rank, world, enc, fe):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    assert tokens.shape[0] == W
     gather_ms = [tm["gather_ev"][0].elapsed_time(tm["gather_ev"][1]) for tm in gathers if "gather_ev" in tm]
+    rehearsal = os.environ.get("AFHIP_BENCH_REHEARSAL") == "1"
     res = {"metric": "audio-seconds encoded/sec (long audio: log-mel + AF-Whisper encoder over window shards + token all-gather)",
-           "value": args.steps * n_clips * 600.0 / elapsed, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+           "value": steps * n_clips * 600.0 / elapsed, "unit": "audio-s/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
            "config": {"workload": "AF3 long audio (BASELINE configs[3]): 4 x 10-min clips = 80 x 30-s windows, window-sharded over the ranks, one all-gather of [750,1280] bf16 tokens per window",
-                      "windows": W, "windows_per_rank": (W + world - 1) // world, "parallelism": f"window shards x{world} + 1 all_gather_into_tensor"}}
+                      "windows": W, "windows_per_rank": (W + world - 1) // world, "windows_uploaded_by_this_rank": hi - lo,
+                      "parallelism": f"window shards x{world} + 1 all_gather_into_tensor"}}
     if gather_ms:
         shard = gathers[0]["gather_bytes"]
         ms = sum(gather_ms) / len(gather_ms)
         sent = (world - 1) * shard
-        res["collective"] = {"op": "all_gather_into_tensor (RCCL over xGMI)" if os.environ.get("AFHIP_BENCH_REHEARSAL") != "1" else "all_gather_into_tensor (gloo REHEARSAL on one GPU: not a measurement)", "shard_bytes": shard, "ms": ms, "bytes_sent_per_rank": sent,
+        res["collective"] = {"op": "all_gather_into_tensor (RCCL over xGMI)" if not rehearsal else "all_gather_into_tensor (gloo REHEARSAL on one GPU: not a measurement)",
+                             "backend": dist.get_backend() if dist is not None else None, "ranks": world,
+                             "shard_bytes": shard, "ms": ms, "ms_min": min(gather_ms), "bytes_sent_per_rank": sent,
                              "GBps_per_rank": sent / (ms * 1e-3) / 1e9, "xgmi_peak_GBps_per_rank": 7 * 153.0,
-                             "frac_of_xgmi": sent / (ms * 1e-3) / 1e9 / (7 * 153.0)}
+                             "frac_of_xgmi": sent / (ms * 1e-3) / 1e9 / (7 * 153.0),
+                             "timed_with": "HIP events on the stream the collective is enqueued on, rank 0"}
     else:
         res["collective"] = None                     # one rank: nothing to gather
-    if not args.no_decode:
+    if with_llm and not args.no_decode:
         model, n_vocab = build_llm_7b(device, enc)
         text_offset = model.vocab_intervals["text"][0][0]
         prompt = syn.make_prompt(LLM_7B["vocab_size"], 32)
@@ -374,29 +490,59 @@ def long_audio_workload(args, device, dist, rank, world, enc, fe):
     return res
 
 
+def decode_only_workload(args, device, enc, fe):
+    """--workload decode: ONLY what a kernel profile of the decode step needs -- encoder + prefill of B clips once, `warmup` untimed
+    steps, then `decode_steps` timed greedy steps (hipGraph replay per token), bf16 or W8A16 weights.  tools/check_profile.py
+    sums the kernels whose call count is a multiple of (warmup + steps) in the rocprofv3 kernel trace of this command and holds
+    the sum against `ms_per_step`."""
+    model, n_vocab = build_llm_7b(device, enc)
+    B, n_steps, warm = args.decode_batch, args.decode_steps, 8
+    g = torch.Generator(device=device).manual_seed(99)
+    wav = torch.randn((B, 480000), generator=g, device=device) * 0.1
+    mel = fe.extract_device(wav, layout="btc", dtype=torch.bfloat16)
+    prompt = syn.make_prompt(LLM_7B["vocab_size"], 32)
+    rows = [1, 5, 7] + [256 + t for t in prompt] + [3, 5, 8] + [0] * 750 + [2]
+    seq = torch.zeros((len(rows), 8), dtype=torch.int64)
+    seq[:, 0] = torch.tensor(rows)
+    start = 3 + len(prompt) + 3
+    batch = {"seqs": seq[None].repeat(B, 1, 1).to(device), "continuous_audio_feats": mel,
+             "continuous_audio_lengths": torch.full((B,), 3000, dtype=torch.long),
+             "continuous_audio_indices": torch.tensor([[b, start, 750] for b in range(B)])}
+    ids = torch.cat([batch["seqs"], model.assistant_token.expand(B, -1, -1)], dim=1)
+    T = ids.shape[1]
+    model.enable_fp8_decode(bool(args.decode_fp8))
+    model.pack(T + n_steps + warm + 64)
+    emb = model._embed(ids, batch)
+    hid, cache = model._forward_hidden(emb, model.new_cache(B, T + n_steps + warm + 16))
+    tok = model.text_token.expand(B, -1, -1).clone()
+    hyp, _, cache = model._greedy_device_loop(tok, cache, "text", warm, poll=10 ** 9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hyp, _, cache = model._greedy_device_loop(hyp[:, -1:, :], cache, "text", n_steps, poll=10 ** 9)
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    wbytes = 1 if args.decode_fp8 else 2
+    step_bytes = decode_bytes_per_step(n_vocab, B, cache.length - n_steps // 2, wbytes)
+    gbs = step_bytes * n_steps / dt_s / 1e9
+    return {"metric": "decode tokens/sec (AF3-7B shape greedy decode loop only)", "value": B * n_steps / dt_s, "unit": "tokens/s", "n_gpus": 1,
+            "steps": n_steps, "warmup": warm, "ms_per_step": dt_s / n_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if not args.decode_fp8 else "bf16 activations, e4m3 weights", "data": "synthetic",
+            "config": {"workload": f"AF3-7B greedy decode only, B={B}, ctx ~{cache.length - n_steps // 2}", "batch": B, "prompt_tokens": T},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": decode_traffic(f"B{B}_{'fp8' if args.decode_fp8 else 'bf16'}"), "bytes_per_step": step_bytes},
+            "cpu_baseline": None}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="30-s clips per GPU per step")
-    ap.add_argument("--no-decode", action="store_true", help="skip the AF3-7B decode leg")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp8 / mixed-length encoder legs (PMC passes: only the headline kernels run)")
-    ap.add_argument("--cpu-clips", type=int, default=8)
-    ap.add_argument("--workload", choices=["encoder", "long_audio"], default="encoder",
-                    help="encoder = BASELINE configs[1] (the headline); long_audio = configs[3]: 4 x 10-min clips, windows sharded over the ranks, one RCCL all-gather")
-    ap.add_argument("--decode-steps", type=int, default=128)
-    args = ap.parse_args()
+    args = parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (plain `python bench.py --gpus N` does it itself)")
     # rehearsal switch (one-GPU box): AFHIP_BENCH_REHEARSAL=1 runs N ranks on ONE device over gloo, to exercise the multi-process
-    # code path (rendezvous, barriers, max-over-ranks, the long-audio gather) where no second GPU exists.  Never a measurement.
+    # code path (launcher, rendezvous, barriers, max-over-ranks, the long-audio gather) where no second GPU exists.  Never a measurement.
     rehearsal = os.environ.get("AFHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -414,6 +560,11 @@ def main():
 
     B, dtype = args.batch, torch.bfloat16
     fe = WhisperFeatureExtractorHIP()
+    if args.workload == "decode":
+        if world != 1:
+            raise SystemExit("--workload decode is a one-GPU profile target")
+        print(json.dumps(decode_only_workload(args, device, build_encoder(device, dtype, None), fe)))
+        return
     if args.workload == "long_audio":
         enc = build_encoder(device, dtype, None)
         res = long_audio_workload(args, device, dist, rank, world, enc, fe)
@@ -575,9 +726,15 @@ def main():
         res["cpu_baseline"] = cb
     elif rank == 0:
         res["cpu_baseline"] = None
-    if rank == 0:
+    if rank == 0 and not args.no_ceiling:
         res["roofline"]["measured_ceiling"] = library_ceiling(device, B)
         res["roofline"]["frac_of_measured_ceiling"] = res["roofline"]["achieved"] / res["roofline"]["measured_ceiling"]["tflops"]
+    if world > 1 and not args.no_long_audio:
+        # the one collective the path has: BASELINE configs[3]'s 80 windows sharded over these ranks, ONE RCCL
+        # all-gather of audio tokens, timed with HIP events -- so a scaling run records that RCCL saw N ranks and what it cost
+        la = long_audio_workload(args, device, dist, rank, world, enc, fe, with_llm=False, steps=max(3, min(args.steps, 10)), warmup=2)
+        if rank == 0:
+            res["long_audio"] = {k: la[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "scaling", "config", "collective")}
     if not args.no_decode:
         del out
         model, n_vocab = build_llm_7b(device, enc)

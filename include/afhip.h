@@ -344,7 +344,11 @@ int afhip_masked_argmax(const float* logits, int rows, int ld, const int32_t* al
  * classifier-free-guidance mix and re-mask of inference_segment folded in (lm/parallel.py:489-492:
  * logits * cfg + cfg_logits * (1 - cfg) as three separately rounded tensor ops, then the modality mask).  One row per
  * (sequence, stream).  The reference draws with torch.multinomial; here the draw is the inverse CDF at a caller-supplied uniform
- * u[r] (same distribution, no RNG stream to reproduce); leave u / token NULL to get only the top-k set and its probabilities. */
+ * u[r] (same distribution, no RNG stream to reproduce); leave u / token NULL to get only the top-k set and its probabilities.
+ * Two stated deviations: (1) softmax(values / temperature) and the CDF are computed in f32 for every model dtype -- the reference
+ * runs them on tensors of the model dtype (lm/parallel.py:603-608), so for bf16 models its probabilities carry bf16 rounding
+ * (<= 2^-8 relative) that these do not; the top-k SET and the mixed logits are rounded exactly as the reference's tensors are.
+ * (2) k <= 64 (the reference accepts any topk; conf/inference.yaml uses 20): larger k returns AFHIP_ERR_INVALID. */
 typedef struct {
     const float* logits;      /* [rows, ld] f32: lm_head output of the conditional half */
     const float* cfg_logits;  /* [rows, ld] f32 of the unconditional (all-pad cache) half, or NULL: no guidance */
@@ -361,6 +365,9 @@ typedef struct {
     float* topk_prob;         /* [rows, k] out (may be NULL): softmax(val / temperature) */
     const float* u;           /* [rows] uniforms in [0,1), or NULL */
     int64_t* token;           /* [rows] out, or NULL: topk_idx[first j with cdf_j > u] */
+    float one_minus_cfg;      /* the weight of cfg_logits.  The reference computes `(1 - cfg)` in Python DOUBLE and the tensor op then
+                                 rounds it to f32 (lm/parallel.py:489-492): pass (float)(1.0 - cfg_as_double).  0 = derive it here as
+                                 (float)(1.0 - (double)cfg), which equals the reference only when cfg is exact in f32 (3.0 is, 1.3 is not) */
 } afhip_sample_args;
 int afhip_sample_topk(const afhip_sample_args* args, void* stream);
 

@@ -116,15 +116,17 @@ def test_delay_interleave_matches_reference():
     assert torch.equal(back, codes) and lens.tolist() == [11, 11]
 
 
+@pytest.mark.parametrize("cfgw", [3.0, 1.3])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_sample_topk_kernel_vs_oracle(dt):
+def test_sample_topk_kernel_vs_oracle(dt, cfgw):
     """afhip_sample_topk on random logits: guidance mix with the reference's roundings, interval masks, top-k order, softmax and
-    the inverse-CDF draw; plus a row with fewer allowed ids than k."""
+    the inverse-CDF draw; plus a row with fewer allowed ids than k.  cfg = 1.3 is not exact in f32: the reference's `(1 - cfg)` is a
+    Python double rounded to f32 once (-0.30000001), not 1.0f - 1.3f (-0.29999995) -- afhip_sample_args.one_minus_cfg carries it."""
     _need_gpu()
     from audio_intelligence_amd import _lib as L
     import ctypes as C
     lib = L.lib()
-    V, rows, k, T, cfgw = 3000, 6, 20, 0.8, 3.0
+    V, rows, k, T = 3000, 6, 20, 0.8
     g = torch.Generator().manual_seed(5)
     lg = (torch.randn(rows, V, generator=g) * 2).to(dt)
     cl = (torch.randn(rows, V, generator=g) * 2).to(dt)
@@ -150,6 +152,7 @@ def test_sample_topk_kernel_vs_oracle(dt):
     o_prob = torch.empty((rows, k), dtype=torch.float32, device=DEV)
     o_tok = torch.empty(rows, dtype=torch.int64, device=DEV)
     a.logits, a.cfg_logits, a.cfg, a.rows, a.ld = lgd.data_ptr(), cld.data_ptr(), cfgw, rows, V
+    a.one_minus_cfg = float(1.0 - cfgw)
     a.allowed, a.n_iv, a.k, a.temperature, a.model_dtype = ivd.data_ptr(), 2, k, T, L.dtype_code(dt)
     a.topk_idx, a.topk_val, a.topk_prob, a.u, a.token = o_idx.data_ptr(), o_val.data_ptr(), o_prob.data_ptr(), ud.data_ptr(), o_tok.data_ptr()
     L.check(lib.afhip_sample_topk(C.byref(a), L.stream_ptr()))

@@ -211,3 +211,40 @@ def test_driver_run_inference_matches_golden_and_isolates_errors(stack_f32, tmp_
         role, modality, ids = res[f"clip{i}"][0]
         assert role == "assistant" and modality == "text"
         assert [row[0] for row in ids] == gold[i], f"clip {i}"
+
+
+def test_decode_graph_and_eager_loops_give_the_same_tokens(stack_f32, monkeypatch):
+    """the captured-hipGraph decode loop (default) against AFHIP_DECODE_GRAPH=0 (eager launches) -- identical ids,
+    identical cache length; and a capture that fails (here: forced) must fall back to eager launches, never abort the segment."""
+    model, pre = stack_f32
+    kw = _to_dev(_sample(1003, pre), torch.float32)
+    cfg = {"text": {"temperature": 0.0, "topk": 20, "cfg": 1, "max_step": 24}, "num_hypo": 1}
+
+    def run():
+        hyps, cache = model.inference_segment(cfg, cache=None, enforce_modality="text", **kw)
+        return hyps[0][0][:, 0].cpu().tolist(), cache.get_seq_length()
+
+    monkeypatch.setenv("AFHIP_DECODE_GRAPH", "1")
+    model._graph_fallback = None
+    ids_g, len_g = run()
+    assert model._graph_fallback is None, model._graph_fallback            # the graph path really ran
+    monkeypatch.setenv("AFHIP_DECODE_GRAPH", "0")
+    ids_e, len_e = run()
+    assert ids_g == ids_e and len_g == len_e
+    monkeypatch.setenv("AFHIP_DECODE_GRAPH", "1")
+
+    class _Boom:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused (test)")
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _Boom)
+    ids_f, len_f = run()
+    assert "capture refused" in (model._graph_fallback or "")
+    assert ids_f == ids_e and len_f == len_e
+
+
+def test_topk_above_64_is_a_clear_error(stack_f32):
+    model, _ = stack_f32
+    lg = torch.randn(1, 1, 8, len(model.vocab), device=DEV)
+    with pytest.raises(ValueError, match="at most 64"):
+        model._logits_to_token(lg, 0.8, 65)
