@@ -64,8 +64,23 @@ template <int ROWBYTES> __device__ __forceinline__ int vtrswz(int row) {
 }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int HD, int NBUF>
+// LAG (bf16, q prescaled to exp2 units, no key split): the softmax with a LAGGED row maximum.  S' = K.Q^T - m_lag leaves the MFMA chain
+// ready for exp2 (the chain starts from a 16-register tuple holding -m_lag instead of zeros), so a key tile costs one v_exp_f32, one
+// v_add_f32 (row sum) and half a v_cvt_pk per score and nothing else: no per-score max, no scale-and-shift fma, no O rescale.  m_lag
+// is the true maximum of the first tile and is raised only when a tile's partial row sum shows a score more than 16 above it
+// (P > 2^16): then that tile is redone with its true maximum, O and l rescaled once.  Mathematically the same softmax (every term
+// carries the same 2^-m_lag factor, which cancels in O / l); P <= 2^16 keeps f32 sums far from overflow, and bf16 P has the same
+// relative precision at any magnitude.
+constexpr float LAG_SUM_LIMIT = 65536.f;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+template <typename T, int HD, int NBUF, bool LAG = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+    static_assert(!LAG || sizeof(T) == 2, "the lagged-maximum softmax is the bf16 throughput form");
     constexpr int SZ = sizeof(T);
     constexpr int KROWB = HD * SZ;             // bytes per K row in LDS
     constexpr int VROWB = KT * SZ;             // bytes per V^T row in LDS
@@ -168,6 +183,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
+    f32x16 cinit;                                   // LAG: -m_lag in all 16 registers, the C input of every tile's first MFMA
+    float m_lag = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[e] = 0.f;
 
     u32x4 rk[NLD], rv[NLD];
     auto load_tile = [&](int t) {
@@ -255,8 +274,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         f32x16 st[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (!LAG) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) st[ks][e] = 0.f;
+                for (int e = 0; e < 16; ++e) st[ks][e] = 0.f;
+            }
             const int krow = ks * 32 + swap23(fr);
 #pragma unroll
             for (int dc = 0; dc < DSTEPS; ++dc) {
@@ -270,7 +291,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ks + krow * KROWB + (((ch + 1) ^ rswz<KROWB>(krow)) << 4));
                     kf = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 }
-                st[ks] = mma16(kf, qf[dc], st[ks]);
+                if constexpr (LAG) st[ks] = mma16(kf, qf[dc], dc == 0 ? cinit : st[ks]);
+                else st[ks] = mma16(kf, qf[dc], st[ks]);
             }
         }
 
@@ -288,42 +310,96 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                     st[ks][e] = ok ? st[ks][e] : -INFINITY;
                 }
         }
-        float mx = -INFINITY;
+        uint32_t pk[2][8];                                   // LAG: P as packed bf16 pairs, the B operand of the O^T MFMAs
+        if constexpr (LAG) {
+            float psum = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[ks][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_i, mx);                 // raw (unscaled) score units
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        if (__any(m_new != m_i)) {                           // the running max moved for some query of this wave
-            const float alpha = __builtin_amdgcn_exp2f((m_i - m_use) * p.scale_log2);   // m_i = -inf -> 0
-            l_i *= alpha;
+                for (int e = 0; e < 16; e += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(st[ks][e]), p1 = __builtin_amdgcn_exp2f(st[ks][e + 1]);
+                    psum += p0;
+                    psum += p1;
+                    pk[ks][e >> 1] = cvt_pk_bf16(p0, p1);
+                }
+            const bool first = t == tbeg;
+            if (first || __any(!(psum <= LAG_SUM_LIMIT))) {    // wave-uniform; NaN-safe (inf - inf cannot occur: m_lag is finite)
+                float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
-            m_i = m_new;
-        }
-        const float moff = -m_use * p.scale_log2;
-        float psum = 0.f;
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[ks][e]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));         // the two lanes of a query agree
+                // raise the lag to this tile's true maximum (first tile: SET it, O and l are still empty)
+                float d = (first || mx > 0.f) ? mx : 0.f;
+                d = (d == -INFINITY) ? 0.f : d;
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_i *= alpha;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                    for (int i = 0; i < DT; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(st[ks][e], p.scale_log2, moff));
-                st[ks][e] = pv;
-                psum += pv;
+                        for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+                }
+                m_lag += d;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cinit[e] = -m_lag;
+                psum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(st[ks][e] - d), p1 = __builtin_amdgcn_exp2f(st[ks][e + 1] - d);
+                        psum += p0;
+                        psum += p1;
+                        pk[ks][e >> 1] = cvt_pk_bf16(p0, p1);
+                    }
             }
-        l_i += psum;
+            l_i += psum;
+        } else {
+            float mx = -INFINITY;
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[ks][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_i, mx);                 // raw (unscaled) score units
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            if (__any(m_new != m_i)) {                           // the running max moved for some query of this wave
+                const float alpha = __builtin_amdgcn_exp2f((m_i - m_use) * p.scale_log2);   // m_i = -inf -> 0
+                l_i *= alpha;
+    #pragma unroll
+                for (int i = 0; i < DT; ++i)
+    #pragma unroll
+                    for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+                m_i = m_new;
+            }
+            const float moff = -m_use * p.scale_log2;
+            float psum = 0.f;
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[ks][e], p.scale_log2, moff));
+                    st[ks][e] = pv;
+                    psum += pv;
+                }
+            l_i += psum;
+
+        }
 
         AT_STAMP(2);
         // ---- O^T += V^T . P^T ; step s covers keys [16s, 16s+16) of the tile ----
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             typename Frag8<T>::type pf;
+            if constexpr (LAG) {
+                const u32x4 w = {pk[s >> 1][4 * (s & 1)], pk[s >> 1][4 * (s & 1) + 1], pk[s >> 1][4 * (s & 1) + 2], pk[s >> 1][4 * (s & 1) + 3]};
+                pf = __builtin_bit_cast(bf16x8, w);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(st[s >> 1][8 * (s & 1) + j]);
+                for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(st[s >> 1][8 * (s & 1) + j]);
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int vrow = dt * 32 + fr;
@@ -560,6 +636,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         if (afhip_first_use_on_device(&attr_done)) {
             (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 2);
             (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_kernel<bf16, 64, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)attn_kernel<float, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 64 * 4);
             (void)hipFuncSetAttribute((const void*)attn_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 4);
         }
@@ -569,7 +646,11 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         if (nbuf == 2) hipLaunchKernelGGL((attn_kernel<TT, HH, 2>), grid, block, lds, s, p);             \
         else hipLaunchKernelGGL((attn_kernel<TT, HH, 1>), grid, block, lds, s, p);                        \
     } while (0)
-    if (a->dtype == AFHIP_BF16) {
+    static int lag = -1;
+    if (lag < 0) { const char* e = getenv("AFHIP_ATTN_LAG"); lag = (e && e[0] == '0') ? 0 : 1; }   // A/B switch
+    if (a->dtype == AFHIP_BF16 && a->hd == 64 && a->q_prescaled && a->key_split == 0 && nbuf == 2 && lag) {
+        hipLaunchKernelGGL((attn_kernel<bf16, 64, 2, true>), grid, block, lds, s, p);      // lagged-maximum softmax (encoder, LayerNorm-folded mode)
+    } else if (a->dtype == AFHIP_BF16) {
         if (a->hd == 64) AFHIP_ATTN_LAUNCH(bf16, 64); else AFHIP_ATTN_LAUNCH(bf16, 128);
     } else {
         if (a->hd == 64) AFHIP_ATTN_LAUNCH(float, 64); else AFHIP_ATTN_LAUNCH(float, 128);

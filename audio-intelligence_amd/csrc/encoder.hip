@@ -159,19 +159,40 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
         a.q_prescaled = (fold && !f8 && w->q_prescaled) ? 1 : 0;
         if (f8) {
             float* sc = ws.stats;                           // [rows] row scales of the activation being multiplied
-            if ((rc = afhip_quant_rows(h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
-            if ((rc = gemm8(ws.ln, sc, w->qkv_w8[l], w->qkv_s8[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, 3 * d, 0, AFHIP_ACT_NONE, s))) return rc;
+            // which projections take e4m3 operands: bit 0 qkv, 1 out, 2 fc1, 3 fc2 (AFHIP_FP8_MASK; the rest run the plain bf16 GEMM
+            // behind an explicit LayerNorm).  Default 14 = out + fc1 + fc2: q / k stay bf16 because the softmax amplifies e4m3 noise
+            // on its logits more than anything downstream (tests/test_gpu_config5.py holds the token-level contract)
+            static int mask = -1;
+            if (mask < 0) {
+                const char* e = getenv("AFHIP_FP8_MASK");
+                mask = e ? atoi(e) : 7;
+                const char* e2 = getenv("AFHIP_FP8_FC2");
+                if (e2 && e2[0] == '1') mask |= 8;
+            }
+            if (mask & 1) {
+                if ((rc = afhip_quant_rows(h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+                if ((rc = gemm8(ws.ln, sc, w->qkv_w8[l], w->qkv_s8[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, 3 * d, 0, AFHIP_ACT_NONE, s))) return rc;
+            } else {
+                if ((rc = afhip_layernorm(h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+                if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            }
             if ((rc = afhip_attention(&a, s))) return rc;
-            if ((rc = afhip_quant_rows(att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
-            if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], h, h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
-            if ((rc = afhip_quant_rows(h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
-            if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
-            // fc2 stays bf16: its input is the [rows, ffn] GELU output, and a per-row quantisation pass over it (492 MB read +
-            // 246 MB written, 109 us at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us); the other three inputs are
-            // d-wide (40-45 us per pass, two of them with the LayerNorm they replace fused in).  AFHIP_FP8_FC2=1 switches it on.
-            static int fc2_f8 = -1;
-            if (fc2_f8 < 0) { const char* e = getenv("AFHIP_FP8_FC2"); fc2_f8 = (e && e[0] == '1') ? 1 : 0; }
-            if (fc2_f8) {
+            if (mask & 2) {
+                if ((rc = afhip_quant_rows(att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
+                if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], h, h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
+            } else {
+                if ((rc = gemm(att, w->out_w[l], w->out_b[l], h, h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
+            }
+            if (mask & 4) {
+                if ((rc = afhip_quant_rows(h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
+                if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
+            } else {
+                if ((rc = afhip_layernorm(h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
+                if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
+            }
+            // fc2's input is the [rows, ffn] GELU output: a per-row quantisation pass over it (492 MB read + 246 MB written, 109 us
+            // at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us) as long as that pass is a launch of its own
+            if (mask & 8) {
                 if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
                 if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
             } else {

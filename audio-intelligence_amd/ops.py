@@ -181,8 +181,9 @@ def transpose_cast(x: torch.Tensor, out_dtype=None):
     return y
 
 
-def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Tensor] = None, causal: bool = False):
-    """Self-attention on fused rows qkv [B,T,3*d] (q|k|v, heads contiguous inside each) -> [B,T,d]."""
+def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Tensor] = None, causal: bool = False, q_prescaled: bool = False):
+    """Self-attention on fused rows qkv [B,T,3*d] (q|k|v, heads contiguous inside each) -> [B,T,d].
+    q_prescaled: the q columns already carry head_dim^-0.5 * log2(e) (afhip_attn_args.q_prescaled)."""
     lib = L.lib()
     _chk(qkv, "attention.qkv")
     B, T, D3 = qkv.shape
@@ -202,11 +203,12 @@ def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Te
     a.o_batch_stride = T * d
     a.q_head_stride = a.kv_head_stride = hd
     a.causal, a.q_pos0, a.scale, a.dtype = int(causal), 0, 1.0 / math.sqrt(hd), L.dtype_code(qkv.dtype)
+    a.q_prescaled = int(q_prescaled)
     L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
     return out
 
 
-def attention_ragged(qkv_rows: torch.Tensor, n_heads: int, lengths: torch.Tensor, max_len: int):
+def attention_ragged(qkv_rows: torch.Tensor, n_heads: int, lengths: torch.Tensor, max_len: int, q_prescaled: bool = False):
     """Self-attention on PACKED fused rows qkv [sum(lengths), 3*d]: sequence b owns rows [off_b, off_b + lengths[b]) with
     off = exclusive cumsum(lengths) (afhip_attn_args.row_off) -> [sum(lengths), d]."""
     lib = L.lib()
@@ -228,6 +230,7 @@ def attention_ragged(qkv_rows: torch.Tensor, n_heads: int, lengths: torch.Tensor
     a.ld_o = d
     a.q_head_stride = a.kv_head_stride = hd
     a.causal, a.q_pos0, a.scale, a.dtype = 0, 0, 1.0 / math.sqrt(hd), L.dtype_code(qkv_rows.dtype)
+    a.q_prescaled = int(q_prescaled)
     L.check(lib.afhip_attention(C.byref(a), L.stream_ptr()))
     return out
 

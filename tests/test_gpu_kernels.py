@@ -704,3 +704,74 @@ def test_gemm_skinny_swiglu_persistent_form_keeps_the_plain_forms_bits(fp8, M, H
     ref = F.silu(h @ gw[:, 0].reshape(I, H).T) * (h @ gw[:, 1].reshape(I, H).T)
     # silu(g) * u: an error of 2^-9 |g| in one factor is multiplied by the other, so the absolute budget scales with the output range
     _check(outs[0], ref, 4e-2 + 4e-3 * float(ref.abs().max()), 3e-2, f"persistent swiglu fp8={fp8} M={M} H={H} I={I}")
+
+
+def _ref_attention_exp2(qs, k, v, key_len=None):
+    """q already carries head_dim^-0.5 * log2(e): P = 2^(q.k) normalised.  [B,T,H,hd] f32 -> [B,T,H*hd], softmax in f64."""
+    B, T, H, hd = qs.shape
+    s = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double()) * math.log(2.0)
+    if key_len is not None:
+        m = torch.arange(k.shape[1])[None, :] >= key_len[:, None]
+        s = s.masked_fill(m[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v.double()).reshape(B, T, H * hd).float()
+
+
+@pytest.mark.parametrize("case", ["plain", "keylen", "rebase_late", "rebase_twice", "first_tile_very_negative", "first_tile_huge", "flat_then_cliff"])
+def test_attention_prescaled_lagged_max(case):
+    """The encoder's throughput form (bf16, hd 64, q prescaled to exp2 units: attn_kernel<..., LAG>): the row maximum is taken from
+    the first key tile and raised only when a later tile holds a score more than 16 (log2 units) above it.  Every branch is forced
+    here (cdna guide rule 26) and held against an f64 softmax over the FULL tensor:
+      rebase_late / rebase_twice: one / two key rows spiked so that chosen later tiles exceed the lag by > 16 -> the redo path with
+        O and l rescaled; first_tile_very_negative: every score of tile 0 is ~ -300 (the lag must be SET to it, not kept at 0, or
+        every P underflows); first_tile_huge: scores ~ +200 in tile 0 (2^200 overflows f32 unless the lag is set first);
+      flat_then_cliff: all scores equal, then far lower (P underflows to 0 after the cliff, l stays the first tiles' sum).
+    The A/B switch AFHIP_ATTN_LAG=0 (plain running-max form) must agree with it to bf16 rounding."""
+    from audio_intelligence_amd import ops
+    B, T, H, hd = 2, 1500, 2, 64
+    d = H * hd
+    c = hd ** -0.5 * math.log2(math.e)
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, T, H, hd, generator=g)
+    k = torch.randn(B, T, H, hd, generator=g)
+    v = torch.randn(B, T, H, hd, generator=g)
+    key_len = None
+    if case == "keylen":
+        key_len = torch.tensor([1500, 77], dtype=torch.int32)
+    elif case == "rebase_late":
+        k[:, 1000] = q[:, 3] * 3.0                     # query 3 (and its neighbours in direction) sees a huge score in tile 15
+    elif case == "rebase_twice":
+        k[:, 200] = q[:, 5] * 2.0
+        k[:, 1300] = q[:, 5] * 6.0
+    elif case == "first_tile_very_negative":
+        u = torch.randn(hd, generator=g)
+        u = u / u.norm()
+        q = q + 60.0 * u                               # every query has a big component along u ...
+        k[:, :64] = k[:, :64] - 45.0 * u               # ... tile 0's keys point the other way (q.k c ~ -300 in log2 units), the rest are ordinary
+    elif case == "first_tile_huge":
+        u = torch.randn(hd, generator=g)
+        u = u / u.norm()
+        q = q + 40.0 * u
+        k[:, :64] = k[:, :64] + 40.0 * u
+    elif case == "flat_then_cliff":
+        q[:] = 1.0
+        k[:, :128] = 0.5
+        k[:, 128:] = -3.0
+    qs = (q * c).to(torch.bfloat16)                    # ONE rounding, after the scale (what the folded q projection emits)
+    kb, vb = k.to(torch.bfloat16), v.to(torch.bfloat16)
+    qkv = torch.cat([qs.reshape(B, T, d), kb.reshape(B, T, d), vb.reshape(B, T, d)], dim=-1).to(_dev())
+    kl = key_len.to(_dev()) if key_len is not None else None
+    out = ops.attention_packed(qkv, H, key_len=kl, q_prescaled=True).float().cpu()
+    ref = _ref_attention_exp2(qs.float(), kb.float(), vb.float(), key_len.long() if key_len is not None else None)
+    assert bool(torch.isfinite(out).all()), case
+    err = (out - ref).abs()
+    # bf16 P and bf16 output: 2e-2 absolute on |v| ~ 1 rows (the tolerance of the non-prescaled encoder test above)
+    assert float(err.max()) <= 2e-2 + 2e-2 * float(ref.abs().max()), (case, float(err.max()))
+    # ragged packed rows through the same kernel
+    if case in ("plain", "rebase_late"):
+        lens = torch.tensor([1500, 640], dtype=torch.int32)
+        rows = torch.cat([qkv[0, :1500], qkv[1, :640]], dim=0).contiguous()
+        o2 = ops.attention_ragged(rows, H, lens, 1500, q_prescaled=True).float().cpu()
+        r2 = _ref_attention_exp2(qs.float()[1:2, :640], kb.float()[1:2, :640], vb.float()[1:2, :640])
+        assert float((o2[:1500] - ref[0]).abs().max()) <= 2e-2 + 2e-2 * float(ref.abs().max())
+        assert float((o2[1500:] - r2[0]).abs().max()) <= 2e-2 + 2e-2 * float(r2.abs().max())
