@@ -9,9 +9,11 @@
 //         Im X[k] = -sum_{n=1..199} w[n] (x[n] - x[400-n])         sin(2 pi k n / 400)
 //     i.e. two [64 x 208] . [208 x 224] products in exact f32 on v_mfma_f32_32x32x2_f32; the folded operand
 //     is built in registers from LDS, the cos / sin tables ([bin][n], 8 consecutive n per lane) stream from L2;
-//   * power -> LDS -> banded mel filter bank (394 non-zeros) -> log10 -> f32 scratch [B,3000,128]
-//     + per-clip running max (ordered-int atomicMax).
-// Pass 2: max(x, clipmax - 8), (x + 4) / 4, cast / transpose into the caller's layout.
+//   * power -> LDS -> banded mel filter bank (394 non-zeros) -> log10 -> (x + 4) / 4 written ONCE, in the caller's layout and
+//     dtype, + per-clip running max of the log10 values (ordered-int atomicMax).
+// Floor fix-up (in place): out = max(out, ((clipmax - 8) + 4) / 4).  Rounding is monotone, so this equals the reference's
+//     (max(x, clipmax - 8) + 4) / 4 bit for bit in f32 and in bf16; the f32 [B,3000,128] intermediate of the old two-pass form
+//     (49 MB written + 49 MB read per 32 clips) is gone: HBM traffic = wav read + mel write + one read of the mel.
 // Replaces transformers feature_extraction_whisper.py:135-170 (called from audio.py:1056-1069).
 #include "common.h"
 #include <math.h>
@@ -57,9 +59,12 @@ __device__ __forceinline__ float float_from_key(int k) { return __int_as_float(k
 // (fixed trip count, masked), so their LDS latency overlaps -- the data-dependent `for k < count` loop this replaces
 // serialised one LDS round trip per band element.  Returns the running max of the values it wrote.
 constexpr int KCMAX = 12;
-template <int NFR, int PITCH>
+// LAYOUT 1: out [B][3000][128] (time-major, what the encoder consumes): a frame's 128 mels are one coalesced row.
+// LAYOUT 0: out [B][128][3000] (the reference's layout): the tile goes through the LDS tile `tr` [NFR][129] and leaves as runs of
+//           NFR consecutive frames per mel.
+template <int NFR, int PITCH, typename TO, int LAYOUT>
 __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
-                                          float* __restrict__ scratch, int b, int t0, int tid) {
+                                          TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int tid) {
     const int m = tid & 127;
     const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
     float wk[KCMAX];
@@ -81,19 +86,31 @@ __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const fl
         for (int k = 0; k < KCMAX; ++k) acc = fmaf(wk[k], pv[k], acc);   // same left-to-right order as the reference's band sum
         // log10 = log2 * log10(2) on v_log_f32 (1 ulp; the argument is >= 1e-10, far from the denormal range)
         const float v = __builtin_amdgcn_logf(fmaxf(acc, 1e-10f)) * 0.30102999566398120f;
-        scratch[((long long)b * NFRAMES + t) * NMEL + m] = v;
+        const float y = (v + 4.0f) / 4.0f;                 // the per-clip floor is applied in place by logmel_floor_kernel
+        if constexpr (LAYOUT == 1) out[((long long)b * NFRAMES + t) * NMEL + m] = from_f32<TO>(y);
+        else tr[f * (NMEL + 1) + m] = y;
         mx = fmaxf(mx, v);
+    }
+    if constexpr (LAYOUT == 0) {
+        __syncthreads();
+        for (int idx = tid; idx < NFR * NMEL; idx += 256) {
+            const int mm = idx / NFR, f = idx % NFR;
+            const int t = t0 + f;
+            if (t < NFRAMES) out[((long long)b * NMEL + mm) * NFRAMES + t] = from_f32<TO>(tr[f * (NMEL + 1) + mm]);
+        }
     }
     return mx;
 }
 
+template <typename TO, int LAYOUT>
 __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wav, int n_samples, long long wav_stride,
-                                                    const float* __restrict__ tab, float* __restrict__ scratch,
+                                                    const float* __restrict__ tab, TO* __restrict__ out,
                                                     int* __restrict__ clipmax) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);          // [NHOPROWS][HOPROW] samples, later [FT][PROW] power
     float* cw = xs + MAIN_FLOATS;                            // [CWMAX] compact mel weights
     int* cband = reinterpret_cast<int*>(cw + Tables::CWMAX); // [NMEL][3] first bin, count, offset
+    float* tr = reinterpret_cast<float*>(cband + 3 * NMEL);  // LAYOUT 0 only: [FT][NMEL + 1] transposition tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int b = blockIdx.y;
@@ -235,8 +252,8 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
         }
     __syncthreads();
 
-    // ---- banded mel + log10 (weights and band table in LDS: no dependent global loads); scratch is [B][3000][128] f32 ----
-    float mx = mel_tail<FT, PROW>(pw, cw, cband, scratch, b, t0, tid);
+    // ---- banded mel + log10 (weights and band table in LDS: no dependent global loads) ----
+    float mx = mel_tail<FT, PROW, TO, LAYOUT>(pw, cw, cband, out, tr, b, t0, tid);
     mx = wave_max(mx);
     if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
 }
@@ -295,8 +312,9 @@ __device__ __forceinline__ void dft5(float& r0, float& i0, float& r1, float& i1,
     r3 = a2r - b2i; i3 = a2i + b2r;
 }
 
+template <typename TO, int LAYOUT>
 __global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
-                                                        const float* __restrict__ tab, float* __restrict__ scratch,
+                                                        const float* __restrict__ tab, TO* __restrict__ out,
                                                         int* __restrict__ clipmax, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef AFHIP_LOGMEL_STAMPS   /* diagnostic build: -DAFHIP_LOGMEL_STAMPS, tools/mel_stamps.py */
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restri
     float* wn = tw + 400;                                    // [400] window
     float* cw = wn + 400;                                    // [CWMAX] compact mel weights
     int* cband = reinterpret_cast<int*>(cw + Tables::CWMAX); // [NMEL][3] first bin, count, offset
+    float* trt = reinterpret_cast<float*>(cband + 3 * NMEL); // LAYOUT 0 only: [FFT_FT][NMEL + 1] transposition tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.y;
     constexpr int NTILE = (NFRAMES + FFT_FT - 1) / FFT_FT;
@@ -483,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restri
     }
     __syncthreads();
 
-    // ---- banded mel + log10; scratch is [B][3000][128] f32 ----
+    // ---- banded mel + log10 + affine, straight into the caller's tensor ----
     LM_STAMP(6);
-    mx = fmaxf(mx, mel_tail<FFT_FT, FFT_PROW>(xs, cw, cband, scratch, b, t0, tid));
+    mx = fmaxf(mx, mel_tail<FFT_FT, FFT_PROW, TO, LAYOUT>(xs, cw, cband, out, trt, b, t0, tid));
     LM_STAMP(7);
     if (next < NTILE) {
         __syncthreads();                                     // the power tile has been consumed: LDS takes the next samples
@@ -502,30 +521,26 @@ __global__ void logmel_init_max(int* clipmax, int B) {
     if (i < B) clipmax[i] = float_order_key(-INFINITY);
 }
 
-// Pass 2: one workgroup = 32 frames x 128 mels of one clip
-template <typename TO, int LAYOUT>
-__global__ __launch_bounds__(256) void logmel_pass2(const float* __restrict__ scratch, const int* __restrict__ clipmax,
-                                                    TO* __restrict__ out) {
-    __shared__ float tile[32][NMEL + 1];
-    const int b = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x;
-    const float floorv = float_from_key(clipmax[b]) - 8.0f;
-    for (int idx = tid; idx < 32 * NMEL; idx += 256) {
-        const int f = idx >> 7, m = idx & 127;
-        const int t = t0 + f;
-        if (t < NFRAMES) {
-            float v = scratch[((long long)b * NFRAMES + t) * NMEL + m];
-            v = (fmaxf(v, floorv) + 4.0f) / 4.0f;
-            if (LAYOUT == 1) out[((long long)b * NFRAMES + t) * NMEL + m] = from_f32<TO>(v);
-            else tile[f][m] = v;
+// Floor fix-up, in place: out = max(out, TO(((clipmax - 8) + 4) / 4)).  A clip's 128 x 3000 values are contiguous in both layouts;
+// one 16-byte chunk per lane, written back only where the floor changed something (silence / padding frames).
+template <typename TO>
+__global__ __launch_bounds__(256) void logmel_floor_kernel(TO* __restrict__ out, const int* __restrict__ clipmax) {
+    constexpr int EPC = 16 / sizeof(TO);
+    constexpr int CHUNKS = NFRAMES * NMEL / EPC;
+    const int b = blockIdx.y;
+    const float fl = ((float_from_key(clipmax[b]) - 8.0f) + 4.0f) / 4.0f;
+    const float flr = to_f32<TO>(from_f32<TO>(fl));          // the floor as the output dtype holds it
+    TO* base = out + (long long)b * NFRAMES * NMEL;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < CHUNKS; c += gridDim.x * 256) {
+        u32x4 raw = ld16(base + (long long)c * EPC);
+        TO* v = reinterpret_cast<TO*>(&raw);
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float x = to_f32<TO>(v[e]);
+            if (x < flr) { v[e] = from_f32<TO>(flr); changed = true; }
         }
-    }
-    if (LAYOUT == 0) {
-        __syncthreads();
-        for (int idx = tid; idx < 32 * NMEL; idx += 256) {
-            const int m = idx >> 5, f = idx & 31;
-            const int t = t0 + f;
-            if (t < NFRAMES) out[((long long)b * NMEL + m) * NFRAMES + t] = from_f32<TO>(tile[f][m]);
-        }
+        if (changed) st16(base + (long long)c * EPC, raw);
     }
 }
 
@@ -577,8 +592,36 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
 
 extern "C" size_t afhip_log_mel_workspace_bytes(int B) {
     if (B <= 0) return 0;
-    return (size_t)B * NFRAMES * NMEL * sizeof(float) + ((size_t)B * sizeof(int) + 255) / 256 * 256;
+    return ((size_t)B * sizeof(int) + 255) / 256 * 256;      // the per-clip running maxima; the log-mel values are written once, in place
 }
+
+namespace {
+template <typename TO, int LAYOUT>
+void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* out, const float* tables, int* clipmax, hipStream_t s) {
+    static int use_dft = -1;
+    if (use_dft < 0) { const char* e = getenv("AFHIP_LOGMEL_DFT"); use_dft = (e && e[0] == '1') ? 1 : 0; }   // A/B switch: the folded-DFT MFMA form
+    if (use_dft) {
+        const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FT * (NMEL + 1) : 0));
+        static unsigned long long attr_done = 0;
+        if (afhip_first_use_on_device(&attr_done))
+            (void)hipFuncSetAttribute((const void*)logmel_pass1<TO, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((logmel_pass1<TO, LAYOUT>), dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+                           tables, out, clipmax);
+    } else {
+        const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FFT_FT * (NMEL + 1) : 0));
+        const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
+        unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
+        // persistent over frame tiles: 2 workgroups per CU in one generation (512 on 256 CUs; 2 waves per SIMD by registers), each walking ceil(94 / gx) tiles
+        int gx = cdiv(512, B);
+        gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);
+        hipLaunchKernelGGL((logmel_pass1_fft<TO, LAYOUT>), dim3(gx, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+                           tables, out, clipmax, dbg);
+    }
+    // floor fix-up: 8 workgroups x 256 lanes x 16 B per pass over a clip's 768 KB (bf16) / 1.5 MB (f32)
+    const int gf = cdiv(NFRAMES * NMEL / (16 / (int)sizeof(TO)), 256 * 4);
+    hipLaunchKernelGGL((logmel_floor_kernel<TO>), dim3(gf, B), dim3(256), 0, s, out, clipmax);
+}
+}  // namespace
 
 extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_stride, void* mel_out, int layout, int out_dtype,
                              const float* tables, void* workspace, void* stream) {
@@ -588,34 +631,16 @@ extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_str
     AFHIP_CHECK(wav_stride >= n_samples, "afhip_log_mel: wav_stride < n_samples");
     AFHIP_CHECK(layout == 0 || layout == 1, "afhip_log_mel: bad layout %d", layout);
     AFHIP_CHECK(out_dtype == AFHIP_F32 || out_dtype == AFHIP_BF16, "afhip_log_mel: bad dtype %d", out_dtype);
-    AFHIP_CHECK(((uintptr_t)tables % 16) == 0, "afhip_log_mel: tables must be 16-byte aligned");
+    AFHIP_CHECK(((uintptr_t)tables % 16) == 0 && ((uintptr_t)mel_out % 16) == 0, "afhip_log_mel: tables and mel_out must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int* clipmax = reinterpret_cast<int*>(workspace);
-    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * sizeof(int) + 255) / 256 * 256);
     hipLaunchKernelGGL(logmel_init_max, dim3(cdiv(B, 256)), dim3(256), 0, s, clipmax, B);
-    static int use_dft = -1;
-    if (use_dft < 0) { const char* e = getenv("AFHIP_LOGMEL_DFT"); use_dft = (e && e[0] == '1') ? 1 : 0; }   // A/B switch: the folded-DFT MFMA form
-    if (use_dft) {
-        const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL);
-        hipLaunchKernelGGL(logmel_pass1, dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
-                           tables, scratch, clipmax);
-    } else {
-        const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL);
-        const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
-        unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
-        // persistent over frame tiles: 2 workgroups per CU in one generation (512 on 256 CUs; 2 waves per SIMD by registers), each walking ceil(94 / gx) tiles
-        int gx = cdiv(512, B);
-        gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);
-        hipLaunchKernelGGL(logmel_pass1_fft, dim3(gx, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
-                           tables, scratch, clipmax, dbg);
-    }
-    const dim3 g2(cdiv(NFRAMES, 32), B);
     if (out_dtype == AFHIP_F32) {
-        if (layout == 0) hipLaunchKernelGGL((logmel_pass2<float, 0>), g2, dim3(256), 0, s, scratch, clipmax, (float*)mel_out);
-        else hipLaunchKernelGGL((logmel_pass2<float, 1>), g2, dim3(256), 0, s, scratch, clipmax, (float*)mel_out);
+        if (layout == 0) logmel_launch<float, 0>(wav, B, n_samples, wav_stride, (float*)mel_out, tables, clipmax, s);
+        else logmel_launch<float, 1>(wav, B, n_samples, wav_stride, (float*)mel_out, tables, clipmax, s);
     } else {
-        if (layout == 0) hipLaunchKernelGGL((logmel_pass2<bf16, 0>), g2, dim3(256), 0, s, scratch, clipmax, (bf16*)mel_out);
-        else hipLaunchKernelGGL((logmel_pass2<bf16, 1>), g2, dim3(256), 0, s, scratch, clipmax, (bf16*)mel_out);
+        if (layout == 0) logmel_launch<bf16, 0>(wav, B, n_samples, wav_stride, (bf16*)mel_out, tables, clipmax, s);
+        else logmel_launch<bf16, 1>(wav, B, n_samples, wav_stride, (bf16*)mel_out, tables, clipmax, s);
     }
     AFHIP_LAUNCH_CHECK();
     return 0;

@@ -45,11 +45,13 @@ const char* afhip_last_error(void);
  * as called from multimodal_io/audio.py:1056-1069 (ContinuousAudioIO.preprocess).
  *   wav      [B, n_samples] f32, n_samples <= 480000 (shorter clips are zero-padded on the fly, :1056-1057)
  *   mel_out  layout 0: [B,128,3000] (extractor layout)   layout 1: [B,3000,128] (preprocess / encode_batch layout)
- *            out_dtype AFHIP_F32 or AFHIP_BF16 (the cast scripts/inference.py:272 applies)
+ *            out_dtype AFHIP_F32 or AFHIP_BF16 (the cast scripts/inference.py:272 applies); 16-byte aligned.
+ *            Written once as (log10(mel) + 4) / 4; the per-clip floor max(x, clipmax - 8) of :160-162 is then applied IN PLACE
+ *            (rounding is monotone, so max-after-rounding equals the reference's round-after-max bit for bit)
  *   tables   device copy of the constant block afhip_log_mel_tables_host() builds on the host from the
  *            [201,128] f32 mel filter bank (transformers/audio_utils.py:638-729): folded-DFT cos/sin tables,
  *            periodic Hann window, filter bands
- *   workspace >= afhip_log_mel_workspace_bytes(B)
+ *   workspace >= afhip_log_mel_workspace_bytes(B): the per-clip running maxima (no intermediate copy of the features)
  */
 size_t afhip_log_mel_tables_bytes(void);
 int afhip_log_mel_tables_host(void* host_buf, const float* filters_host);
