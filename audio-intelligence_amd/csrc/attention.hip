@@ -571,6 +571,8 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 
 }  // namespace
 
+bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s);   // attention_enc.hip: the one-wave-per-SIMD encoder form
+
 extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_attention: null args");
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_attention: bad dtype %d", a->dtype);
@@ -587,6 +589,9 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
                 "afhip_attention: strides must keep 16-byte alignment");
     AFHIP_CHECK(a->ld_o >= a->hd, "afhip_attention: ld_o too small");
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
+
+    if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
+    if (afhip_attention_enc64(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
 
     AttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;

@@ -775,3 +775,39 @@ def test_attention_prescaled_lagged_max(case):
         r2 = _ref_attention_exp2(qs.float()[1:2, :640], kb.float()[1:2, :640], vb.float()[1:2, :640])
         assert float((o2[:1500] - ref[0]).abs().max()) <= 2e-2 + 2e-2 * float(ref.abs().max())
         assert float((o2[1500:] - r2[0]).abs().max()) <= 2e-2 + 2e-2 * float(r2.abs().max())
+
+
+@pytest.mark.parametrize("T", [1, 63, 64, 65, 130, 257, 700])
+def test_attention_prescaled_small_and_ragged_shapes(T):
+    """The one-wave-per-SIMD encoder kernel (attention_enc.hip) at the edges of its tiling: fewer queries than a workgroup's 256, key
+    counts on both sides of the 64-key tile (the last tile's out-of-range keys are copies of the last live key whose V rows arrive as
+    zeros and whose terms are removed from the row sums), one live key, more heads x clips than a multiple of 8 (the non-XCD grid order)
+    and the A/B switch AFHIP_ATTN_ENC64=0 (plain kernel) on the same inputs."""
+    from audio_intelligence_amd import ops
+    B, H, hd = 3, 3, 64
+    d = H * hd
+    c = hd ** -0.5 * math.log2(math.e)
+    g = torch.Generator().manual_seed(T)
+    q = torch.randn(B, T, H, hd, generator=g)
+    k = torch.randn(B, T, H, hd, generator=g)
+    v = torch.randn(B, T, H, hd, generator=g)
+    qs = (q * c).to(torch.bfloat16)
+    kb, vb = k.to(torch.bfloat16), v.to(torch.bfloat16)
+    qkv = torch.cat([qs.reshape(B, T, d), kb.reshape(B, T, d), vb.reshape(B, T, d)], dim=-1).to(_dev())
+    key_len = torch.tensor([T, max(1, T // 2 + 1), 1], dtype=torch.int32)
+    for kl in (None, key_len):
+        out = ops.attention_packed(qkv, H, key_len=kl.to(_dev()) if kl is not None else None, q_prescaled=True).float().cpu()
+        ref = _ref_attention_exp2(qs.float(), kb.float(), vb.float(), kl.long() if kl is not None else None)
+        assert bool(torch.isfinite(out).all()), (T, kl)
+        err = (out - ref).abs()
+        assert float(err.max()) <= 2e-2 + 2e-2 * float(ref.abs().max()), (T, kl, float(err.max()))
+    # packed rows
+    lens = key_len
+    rows = torch.cat([qkv[b, : int(lens[b])] for b in range(B)], dim=0).contiguous()
+    o2 = ops.attention_ragged(rows, H, lens, T, q_prescaled=True).float().cpu()
+    off = 0
+    for b in range(B):
+        n = int(lens[b])
+        r = _ref_attention_exp2(qs.float()[b:b + 1, :n], kb.float()[b:b + 1, :n], vb.float()[b:b + 1, :n])[0]
+        assert float((o2[off: off + n] - r).abs().max()) <= 2e-2 + 2e-2 * float(r.abs().max()), (T, b)
+        off += n
