@@ -1,19 +1,27 @@
-// Encoder self-attention at head_dim 64 (bf16, q prescaled to exp2 units, per-clip key length): the ONE-WAVE-PER-SIMD form.
+// Encoder self-attention at head_dim 64 (bf16, q prescaled to exp2 units, per-clip key length): the ONE-WAVE-PER-SIMD, PERSISTENT form.
 // Same arithmetic as attn_kernel<bf16, 64, 2, LAG> (attention.hip): S^T = K . Q^T - m_lag with the query on the MFMA lane, P = exp2(S')
 // straight out of the accumulators, O^T += V^T . P^T, lagged row maximum (raised only when a tile's partial row sum exceeds 2^16).
 //
 // Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"; MI355X_MICROARCH.md issue prices):
 //   * workgroup = 4 waves = 256 queries of one (clip, head); a wave owns 64 queries as TWO 32-query blocks a, b and the whole
 //     512-register file.  A K or V fragment read from LDS serves both blocks: 16 KB of LDS reads per 32 MFMAs instead of per 16.
-//   * K / V tiles of 64 keys arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction) into a ring of 4 stages, three
-//     tiles ahead of the arithmetic; ONE barrier per key tile, counted vmcnt (4 DMA instructions per wave per tile).
+//   * one workgroup per CU walks the (query tile, head, clip) blocks; the NEXT block's Q rows and first three K / V tiles are requested
+//     before the current block's epilogue runs (measured: with one workgroup per block, 5 us of launch ramp, Q / first-tile latency and
+//     epilogue per block ran with nothing beside them -- a fifth of the kernel).
+//   * K / V tiles of 64 keys arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, issued from inline asm) into a ring of
+//     4 stages, three tiles ahead of the arithmetic; ONE barrier per key tile, counted vmcnt (4 DMA instructions per wave per tile).
 //   * per tile the wave runs two SLOTS of 16 MFMAs, each beside the softmax (32 x v_exp_f32, 32 x v_add_f32, 16 x v_cvt_pk) of ONE
 //     query block, software-pipelined across tiles so that every softmax has 16 independent MFMAs to hide behind:
-//         slot 1:  S_b(t) = K(t).Q_b^T     O_b += V(t-1).P_b(t-1)     ||  softmax of S_a(t)   -> P_a(t)
+//         slot 1:  S_b(t) = K(t).Q_b^T     O_b += V(t-1).P_b(t-1)     ||  softmax of S_a(t)   -> P_a(t)   ||  fragment reads K(t+1), V(t)
 //         slot 2:  S_a(t+1) = K(t+1).Q_a^T  O_a += V(t).P_a(t)        ||  softmax of S_b(t)   -> P_b(t)
-//     (issue budget per MFMA gap: 2 exp (16 cycles) + 2 add + 1 cvt (12) + the MFMA's own 8 = 36 of 32: the VALU, not the matrix pipe,
-//     is the floor at head_dim 64 -- 0.89 of the MFMA roof if perfectly packed.)
+//     Every MFMA gap is pinned in the source by a scheduling fence: [MFMA] [2 v_exp, 2 v_add, 1 v_cvt_pk] [<= 3 LDS reads]  (issue
+//     budget 8 + 16 + 12 = 36 cycles of the MFMA's 32: at head_dim 64 the VALU, not the matrix pipe, is the floor -- 0.89 of the roof).
+//   * the accumulator file is ASM-OWNED: O, the Q / K / V fragments live at literal a[..] registers named in the asm text (hipcc's own
+//     allocation put S' in AGPRs -- 64 v_accvgpr_read per slot -- and bounced fragments between the two files); S', the chains' C input
+//     and the packed P are ordinary compiler-managed arch VGPRs, because the VALU reads and writes them.
 //   * the rare "raise the lag" path sits in its own basic block at the END of a slot, so the slots stay straight-line code.
+//   * keys past the clip's length in the last tile are copies of the last live key (clamped K rows) whose V rows arrive as zeros (out
+//     of range of the V buffer descriptor): they add nothing to O and their equal terms are taken out of the row sums.
 //   * O leaves through LDS as whole 128-byte rows (16 B per lane) instead of 8-byte row-strided stores.
 #include "common.h"
 #include <type_traits>
@@ -26,7 +34,10 @@ constexpr int E_ROWB = E_HD * 2;                 // bytes per K / V row in LDS
 constexpr int E_TILEB = E_KT * E_ROWB;           // 8 KiB
 constexpr int E_STAGEB = 2 * E_TILEB;            // K tile + V tile
 constexpr int E_NST = 4;
-constexpr int E_LDS = E_NST * E_STAGEB;          // 64 KiB
+constexpr int E_RING = E_NST * E_STAGEB;         // 64 KiB
+constexpr int E_OROW = 144;                      // O staging row: 128 B + 16 B pad
+constexpr int E_QOFF = E_RING + 4 * 64 * E_OROW; // + 36 KiB of O staging (one private 64-row area per wave)
+constexpr int E_LDS = E_QOFF + E_QT * E_ROWB;    // + 32 KiB: the block's Q rows (each wave DMAs and reads its own 64)
 constexpr float E_LAG_LIMIT = 65536.f;
 
 struct EncAttnP {
@@ -37,12 +48,10 @@ struct EncAttnP {
     long long ld_q, ld_kv, ld_o;        // elements
     long long q_bs, kv_bs, o_bs;
     long long q_hs, kv_hs, o_hs;
-    int n_qt;
+    int n_qt, n_blk;
 };
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int e_swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ uint32_t e_cvt_pk(float lo, float hi) {
@@ -59,6 +68,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#define E_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define E_BARRIER()                               \
     do {                                          \
         __builtin_amdgcn_sched_barrier(0);        \
@@ -66,295 +76,29 @@ __device__ __forceinline__ void static_for(F&& f) {
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// VAR: tuning / ablation switches (AFHIP_ENC64_VAR): bit 0 = softmax VALU software-pipelined by one MFMA gap (exps of pair i beside the
-// adds / cvt of pair i-1, two partial sums); bit 1 = the tile's 4 DMA instructions spread over slot 2's gaps instead of a burst at the top;
-// bit 2 (TIMING ONLY, wrong results) = no softmax; bit 3 (TIMING ONLY) = no DMA in the loop
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
-
-    // (query tile, head, clip) with the x-tiles of one (clip, head) back to back on ONE XCD (attention.hip)
-    const int nh = p.n_h * p.B;
-    int xt, hb;
-    if ((nh & 7) == 0) {
-        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
-        xt = r % p.n_qt;
-        hb = (r / p.n_qt) * 8 + xcd;
-    } else {
-        xt = blockIdx.x % p.n_qt;
-        hb = blockIdx.x / p.n_qt;
-    }
-    const int b = hb / p.n_h, h = hb % p.n_h;
-    const int q0 = xt * E_QT;
-    long long q_off = (long long)b * p.q_bs, kv_off = (long long)b * p.kv_bs, o_off = (long long)b * p.o_bs;
-    int Tq = p.Tq, klen = p.Tk;
-    if (p.key_len) { const int kl = p.key_len[b]; klen = kl < klen ? kl : klen; }
-    if (p.row_off) {
-        const long long r = p.row_off[b];
-        q_off = r * p.ld_q; kv_off = r * p.ld_kv; o_off = r * p.ld_o;
-        Tq = p.key_len[b];
-    }
-    if (q0 >= Tq) return;                  // packed batches: query tile past this clip (workgroup-uniform, before any barrier)
-    const char* qb_ = p.q + (q_off + (long long)h * p.q_hs) * 2;
-    const char* kb_ = p.k + (kv_off + (long long)h * p.kv_hs) * 2;
-    const char* vb_ = p.v + (kv_off + (long long)h * p.kv_hs) * 2;
-    const int nt = klen > 0 ? (klen + E_KT - 1) / E_KT : 0;
-
-    // ---- LDS-DMA (buffer_load_dwordx4 ... lds) as INLINE ASM: hipcc's waitcnt pass drains every LDS-DMA it knows about (vmcnt(0)) in
-    //      front of the transposed LDS reads below; issued from asm the stream is invisible to it and stays in flight behind the counted
-    //      vmcnt of the tile loop (cdna guide 5.7).  A wave-instruction fills 8 LDS rows of 128 B; lane (lrow, slot) writes slot `slot` of
-    //      row r0 + lrow with SOURCE chunk slot ^ swz(row) (linear image, swizzle on the source address).  Wave w owns rows 16 w .. 16 w + 15
-    //      of every K and V tile (two instructions each).  Keys past klen re-read the last live row (0 x garbage must stay 0). ----
-    const int lrow = lane >> 3, lslot = lane & 7;
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    auto make_rsrc = [&](const char* base, int nrec) {
-        const unsigned long long a = (unsigned long long)base;
-        v4i_t r;
-        r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-        r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));      // stride 0
-        r[2] = __builtin_amdgcn_readfirstlane(nrec);                           // num_records (bytes): offsets at or past it read as 0
-        r[3] = 0x00020000;
-        return r;
-    };
-    const int ldkv2 = (int)(p.ld_kv * 2);
-    // K rows past klen re-read the last live row (their scores equal the last live key's: finite, and removed from the row sums below);
-    // V rows past klen are OUT OF RANGE of the V descriptor and arrive as zeros, so those keys add nothing to O
-    const v4i_t krsrc = make_rsrc(kb_, 0x7fffffff), vrsrc = make_rsrc(vb_, (klen > 0 ? (klen - 1) * ldkv2 : 0) + E_ROWB);
-    const int lds_base = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
-    auto dma16 = [&](const v4i_t& rsrc, int voff, int lds_addr) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-    };
-    // one of the 4 DMA instructions of tile t (j = 0..3: K rows 0-7, V rows 0-7, K rows 8-15, V rows 8-15 of this wave's 16 rows)
-    auto dma_piece = [&](int t, const int j) {
-        const int tt = t < nt ? t : nt - 1;
-        const int base = __builtin_amdgcn_readfirstlane(lds_base + (t & (E_NST - 1)) * E_STAGEB + wave * 2048);
-        const int u = j >> 1;
-        const int row = wave * 16 + u * 8 + lrow;
-        const int key = tt * E_KT + row;
-        if ((j & 1) == 0) {
-            const int keyc = key < klen ? key : klen - 1;
-            dma16(krsrc, keyc * ldkv2 + (lslot ^ ((row >> 1) & 7)) * 16, base + u * 1024);
-        } else {
-            dma16(vrsrc, key * ldkv2 + (lslot ^ (((row >> 1) & 1) << 2)) * 16, base + E_TILEB + u * 1024);
-        }
-    };
-    auto dma_tile = [&](int t, int stage) {
-        const int ks = __builtin_amdgcn_readfirstlane(lds_base + stage * E_STAGEB + wave * 2048);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = wave * 16 + u * 8 + lrow;
-            const int key = t * E_KT + row;
-            const int keyc = key < klen ? key : klen - 1;
-            const int kc = lslot ^ ((row >> 1) & 7);                 // rswz<128>
-            const int vc = lslot ^ (((row >> 1) & 1) << 2);          // vtrswz<128>
-            dma16(krsrc, keyc * ldkv2 + kc * 16, ks + u * 1024);
-            dma16(vrsrc, key * ldkv2 + vc * 16, ks + E_TILEB + u * 1024);
-        }
-    };
-    // tiles past the end re-fetch the last one: the vmcnt bookkeeping stays uniform and every stage always holds finite data
-    auto dma_clamped = [&](int t) { dma_tile(t < nt ? t : nt - 1, t & (E_NST - 1)); };
-
-    // ---- the accumulator file is ASM-OWNED (literal register names; hipcc allocates none of it: its own choice put S' in AGPRs, 64
-    //      v_accvgpr_read per slot, and bounced fragments between the files).  Map:
-    //        a[0:31]   O_a^T (d tiles 0, 1)      a[32:63]  O_b^T          a[64:79] Q_a fragments (4 x 4)   a[80:95] Q_b
-    //        a[96:127] K fragment set A (8 x 4)  a[128:159] set B        a[160:191] V fragment set A      a[192:223] set B
-    //      S', the chains' C input and the packed P stay in compiler-managed arch VGPRs (they are VALU operands). ----
-    constexpr int A_OA = 0, A_OB = 32, A_QA = 64, A_QB = 80, A_KF = 96, A_VF = 160;
+// accumulator-file map (first register of each object)
+constexpr int A_OA = 0, A_OB = 32, A_QA = 64, A_QB = 80, A_KF = 96, A_VF = 160;
+//   a[0:31] O_a^T (d tiles 0, 1)   a[32:63] O_b^T   a[64:79] Q_a fragments (4 x 4)   a[80:95] Q_b
+//   a[96:127] K fragment set 0 (8 x 4)   a[128:159] set 1   a[160:191] V fragment set 0   a[192:223] set 1
 // (immediates above 64 print in hex: `a[0x50]` assembles, `a0x50` does not -- always the bracket form)
 #define E_ACC_WRITE(IDX, VAL) asm volatile("v_accvgpr_write_b32 a[%0], %1" :: "n"(IDX), "v"(VAL) : "a255")
 #define E_ACC_READ(DST, IDX) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(DST) : "n"(IDX))
-    // ---- Q fragments (B operand of S^T), both query blocks, resident in a[64:95] ----
-    {
-        int ra = q0 + wave * 64 + fr, rb = ra + 32;
-        ra = ra < Tq ? ra : Tq - 1;
-        rb = rb < Tq ? rb : Tq - 1;
-        const __bf16* pa = reinterpret_cast<const __bf16*>(qb_) + (long long)ra * p.ld_q;
-        const __bf16* pb = reinterpret_cast<const __bf16*>(qb_) + (long long)rb * p.ld_q;
-        u32x4 qa[4], qb[4];
-#pragma unroll
-        for (int dc = 0; dc < 4; ++dc) {
-            qa[dc] = *reinterpret_cast<const u32x4*>(pa + dc * 16 + fh * 8);
-            qb[dc] = *reinterpret_cast<const u32x4*>(pb + dc * 16 + fh * 8);
-        }
-        static_for<0, 16>([&](auto it) {
-            constexpr int i = decltype(it)::value;
-            const uint32_t xa = qa[i >> 2][i & 3], xb = qb[i >> 2][i & 3];    // (asm operands inside a generic lambda do not capture by themselves)
-            E_ACC_WRITE(A_QA + i, xa);
-            E_ACC_WRITE(A_QB + i, xb);
-        });
-    }
-    if (nt == 0) {
-        // no live key: zeros (l = 0), exactly what the plain kernel stores
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int qrow = q0 + wave * 64 + blk * 32 + fr;
-            if (qrow < Tq) {
-                __bf16* op = reinterpret_cast<__bf16*>(p.o) + o_off + (long long)qrow * p.ld_o + (long long)h * p.o_hs;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(op + fh * 32 + c * 8) = u32x4{0, 0, 0, 0};
-            }
-        }
-        return;
-    }
-    // O = 0, V fragment sets = 0 (the first slot multiplies V(-1) = 0 by P_b(-1) = 0)
-    {
-        const uint32_t zero = 0u;
-        static_for<0, 64>([&](auto it) { const uint32_t z = zero; E_ACC_WRITE(A_OA + decltype(it)::value, z); });
-        static_for<0, 64>([&](auto it) { const uint32_t z = zero; E_ACC_WRITE(A_VF + decltype(it)::value, z); });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the Q loads are the only compiler-counted VMEM ops: retired before the
-    __builtin_amdgcn_sched_barrier(0);                          // hand-counted DMA stream starts
-
-    f32x16 sa[2], sb[2];                    // S'^T [key sub-tile]                            (VGPR)
-    f32x16 ca, cb;                          // C input of each chain: -m_lag                  (VGPR)
-    u32x4 pka[4], pkb[4];                   // P as packed bf16: the B operand of PV k-step s (VGPR)
-    float ml_a = 0.f, ml_b = 0.f, l_a = 0.f, l_b = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { ca[e] = 0.f; cb[e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pka[i] = u32x4{0, 0, 0, 0}; pkb[i] = u32x4{0, 0, 0, 0}; }
-
-#define E_FENCE() __builtin_amdgcn_sched_barrier(0)
-    // MFMA forms (KF / Q / VF / O = first register of the operand's tuple in the accumulator file)
+// MFMA forms (KF / Q / VF / O = first register of the operand's tuple in the accumulator file).  S_FIRST opens a chain from the VGPR tuple
+// C (written by VALU code shortly before: s_nop 1); the others accumulate in place.
+#if defined(E_TIMING_S_AGPR) || defined(E_TIMING_NOEXP) || defined(E_TIMING_NOADD) || defined(E_TIMING_NOCVT)
+#define E_REBASE_COND(PS) (__any((PS) == -12345.f))
+#else
+#define E_REBASE_COND(PS) (__any(!((PS) <= E_LAG_LIMIT)))
+#endif
+#ifdef E_TIMING_S_AGPR   /* TIMING EXPERIMENT ONLY (wrong results): the S' chains accumulate into a[224:239] instead of VGPRs */
+#define E_MFMA_S_FIRST(S, KF, Q, C) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[224:239], a[%2:%3], a[%4:%5], a[224:239]" : "+v"(S) : "v"(C), "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
+#define E_MFMA_S_ACC(S, KF, Q) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], a[%1:%2], a[%3:%4], a[224:239]" : "+v"(S) : "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
+#else
 #define E_MFMA_S_FIRST(S, KF, Q, C) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%2:%3], a[%4:%5], %1" : "=&v"(S) : "v"(C), "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
 #define E_MFMA_S_ACC(S, KF, Q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%1:%2], a[%3:%4], %0" : "+v"(S) : "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
+#endif
 #define E_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 a[%1:%2], a[%3:%4], %0, a[%1:%2]" :: "v"(PF), "n"(O), "n"((O) + 15), "n"(VF), "n"((VF) + 3) : "memory")
-
-    // fragment read addresses: lane part in a VGPR, (ring stage, sub-tile, k-step) part in the instruction's 16-bit offset
-    const int krow0 = e_swap23(fr);
-    int kaddr[4];
-#pragma unroll
-    for (int dc = 0; dc < 4; ++dc) kaddr[dc] = lds_base + krow0 * E_ROWB + (((dc * 2 + fh) ^ ((krow0 >> 1) & 7)) << 4);   // sub-tile 1: + 32 rows = + 4096
-    int vaddr[2];
-    {
-        const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, gsel = (lane >> 4) & 1;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int col = dt * 32 + gsel * 16 + tp * 4;
-            const int key0 = fh * 8 + tq;                       // k-step s: + 16 rows = + 2048; second half: + 4 rows = + 512 (same swizzle)
-            vaddr[dt] = lds_base + E_TILEB + key0 * E_ROWB + (((col >> 3) ^ (((key0 >> 1) & 1) << 2)) << 4) + (col & 7) * 2;
-        }
-    }
-    // fragment i of K set SET from ring stage STAGE: ds_read_b128 straight into a[..]
-#define E_READ_K(SET, I, STAGE) asm volatile("ds_read_b128 a[%1:%2], %0 offset:%3" :: "v"(kaddr[(I) & 3]), "n"(A_KF + (SET) * 32 + (I) * 4), "n"(A_KF + (SET) * 32 + (I) * 4 + 3), \
-                                             "n"((STAGE) * E_STAGEB + ((I) >> 2) * 4096) : "memory")
-    // fragment i = (k-step i >> 1, d tile i & 1) of V set SET: two transposed 8-byte reads into the halves of a[..]
-#define E_READ_V(SET, I, STAGE) asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%5\n\tds_read_b64_tr_b16 a[%3:%4], %0 offset:%6" :: "v"(vaddr[(I) & 1]), \
-                                             "n"(A_VF + (SET) * 32 + (I) * 4), "n"(A_VF + (SET) * 32 + (I) * 4 + 1), "n"(A_VF + (SET) * 32 + (I) * 4 + 2), "n"(A_VF + (SET) * 32 + (I) * 4 + 3), \
-                                             "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048), "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048 + 512) : "memory")
-
-    // the two scores of MFMA gap i of a slot: P = exp2(S'), row-sum partial, packed bf16.  pk[s][j] holds registers 8 (s & 1) + 2 j, + 1
-    // of sub-tile s >> 1, i.e. pk[s] is the 8 keys of PV k-step s.
-    float pend0 = 0.f, pend1 = 0.f, psum2 = 0.f;     // VAR & 1: the pair exponentiated in the previous gap, second partial sum
-    auto soft2 = [&](const int i, const f32x16 (&s)[2], u32x4 (&pk)[4], float& psum) __attribute__((always_inline)) {
-        if constexpr (VAR & 4) return;
-        const int ks = i >> 3, e = 2 * (i & 7);
-        if constexpr (VAR & 1) {
-            // gap i: exps of pair i; adds + cvt of pair i - 1 (pair 15 is finished by soft_tail)
-            const float q0 = pend0, q1 = pend1;
-            pend0 = __builtin_amdgcn_exp2f(s[ks][e]);
-            pend1 = __builtin_amdgcn_exp2f(s[ks][e + 1]);
-            if (i > 0) {
-                const int j = i - 1;
-                psum += q0;
-                psum2 += q1;
-                uint32_t w = e_cvt_pk(q0, q1);
-                asm volatile("" : "+v"(w));
-                pk[(j >> 3) * 2 + ((j & 7) >> 2)][j & 3] = w;
-            }
-        } else {
-            const float p0 = __builtin_amdgcn_exp2f(s[ks][e]), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1]);
-            psum += p0;
-            psum += p1;
-            uint32_t w = e_cvt_pk(p0, p1);
-            asm volatile("" : "+v"(w));        // pinned here: the rare path overwrites P, and hipcc would sink the slot's 16 v_cvt_pk below its branch
-            pk[ks * 2 + ((i & 7) >> 2)][i & 3] = w;
-        }
-    };
-    auto soft_tail = [&](u32x4 (&pk)[4], float& psum) __attribute__((always_inline)) {
-        if constexpr ((VAR & 1) && !(VAR & 4)) {
-            psum += pend0;
-            psum2 += pend1;
-            uint32_t w = e_cvt_pk(pend0, pend1);
-            asm volatile("" : "+v"(w));
-            pk[3][3] = w;
-            psum += psum2;
-            psum2 = 0.f;
-        }
-    };
-    // the rare path: raise the lag of one query block (O at a[OBASE .. OBASE + 31]) to the true maximum of this tile and redo its P
-    auto rebase = [&](auto obase_tag, const f32x16 (&s)[2], u32x4 (&pk)[4], f32x16& c, float& ml, float& l, float& d_out) -> float {
-        constexpr int OBASE = decltype(obase_tag)::value;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[ks][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float d = mx > 0.f ? mx : 0.f;
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        l *= alpha;
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // the block's last O MFMA -> v_accvgpr_read (18 wait states)
-        static_for<0, 32>([&](auto it) {
-            constexpr int i = decltype(it)::value;
-            float x;
-            E_ACC_READ(x, OBASE + i);
-            x *= alpha;
-            E_ACC_WRITE(OBASE + i, x);
-        });
-        asm volatile("s_nop 1" ::: "memory");
-        ml += d;
-        d_out = d;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) c[e] = -ml;
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ks = i >> 3, e = 2 * (i & 7);
-            const float p0 = __builtin_amdgcn_exp2f(s[ks][e] - d), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1] - d);
-            psum += p0;
-            psum += p1;
-            pk[ks * 2 + ((i & 7) >> 2)][i & 3] = e_cvt_pk(p0, p1);
-        }
-        return psum;
-    };
-    // Last, partly filled tile: the keys past klen are copies of key klen - 1 (same K row -> bit-identical S'), with zero V rows.  They add
-    // nothing to O; their equal terms exp2(S'_last - d) are taken out of this lane's row-sum partial here (each half of a lane pair sums 32
-    // of the tile's 64 keys: count the copies this half holds).  Runs once per query block per workgroup, in a basic block of its own.
-    auto dup_sum = [&](const f32x16 (&s)[2], float d) -> float {
-        const int kk = (klen - 1) - (nt - 1) * E_KT;       // position of the last live key inside the last tile
-        float v = 0.f;
-        int mine = 0, cnt = 0;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = ks * 32 + e_swap23(mfma32_row(e, lane));
-                v = key == kk ? s[ks][e] : v;
-                mine |= key == kk ? 1 : 0;
-                cnt += key > kk ? 1 : 0;
-            }
-        const float vo = __shfl_xor(v, 32, 64);
-        const float sl = mine ? v : vo;                    // the last live key sits in exactly one half of the pair
-        return (float)cnt * __builtin_amdgcn_exp2f(sl - d);
-    };
-    const bool has_edge = (klen % E_KT) != 0;
-
-    // ---- prologue: tiles 0, 1, 2 on their way; the true row maxima of tile 0 become the lags; S'_a(0) ----
-    dma_clamped(0);
-    dma_clamped(1);
-    dma_clamped(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile 0 of this wave has landed
-    E_BARRIER();                                               // ... and everybody's
-    static_for<0, 8>([&](auto it) { constexpr int i = decltype(it)::value; (void)&kaddr; E_READ_K(0, i, 0); });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    E_FENCE();
-    // S' chains of one block (KSET = fragment set, Q = first register of its Q fragments)
+// S' chains of one block from K set KSET (Q = first register of the block's Q fragments)
 #define E_CHAINS(S, KSET, Q, C)                                                              \
     do {                                                                                      \
         E_MFMA_S_FIRST(S[0], A_KF + (KSET) * 32, Q, C);                                       \
@@ -366,27 +110,8 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
         E_MFMA_S_ACC(S[1], A_KF + (KSET) * 32 + 24, (Q) + 8);                                 \
         E_MFMA_S_ACC(S[1], A_KF + (KSET) * 32 + 28, (Q) + 12);                                \
     } while (0)
-    {
-        E_CHAINS(sa, 0, A_QA, ca);
-        E_CHAINS(sb, 0, A_QB, cb);
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // MFMA results -> VALU readers (18 wait states for a 16-pass MFMA)
-        E_FENCE();
-        float ma = -INFINITY, mb = -INFINITY;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { ma = fmaxf(ma, sa[ks][e]); mb = fmaxf(mb, sb[ks][e]); }
-        ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
-        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-        ml_a = ma; ml_b = mb;                                  // finite: every key row of tile 0 is a live row (copies included)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { ca[e] = -ml_a; cb[e] = -ml_b; }
-        E_FENCE();
-        E_CHAINS(sa, 0, A_QA, ca);
-    }
-
-    // one MFMA of a slot: MFMAs 0..7 are the S' chains (sub-tile 0: 0..3, sub-tile 1: 4..7) of the block whose Q sits at QB, from K set
-    // KSET; 8..15 are O (at OB) += V (set VSET) . P
+// one MFMA of a slot: MFMAs 0..7 are the S' chains (sub-tile 0: 0..3, sub-tile 1: 4..7) of the block whose Q sits at QB, from K set KSET;
+// 8..15 are O (at OB) += V (set VSET) . P
 #define E_SLOT_MFMA(I, S, KSET, QB, C, OB, VSET, PK)                                                           \
     do {                                                                                                        \
         if constexpr ((I) < 8) {                                                                                \
@@ -396,96 +121,390 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
             E_MFMA_O((OB) + (((I) - 8) & 1) * 16, A_VF + (VSET) * 32 + ((I) - 8) * 4, PK[((I) - 8) >> 1]);     \
         }                                                                                                       \
     } while (0)
+// fragment i of K set SET from ring stage STAGE: ds_read_b128 straight into a[..] (kaddr = lane part, the rest in the 16-bit offset)
+#define E_READ_K(SET, I, STAGE) asm volatile("ds_read_b128 a[%1:%2], %0 offset:%3" :: "v"(kaddr[(I) & 3]), "n"(A_KF + (SET) * 32 + (I) * 4), "n"(A_KF + (SET) * 32 + (I) * 4 + 3), \
+                                             "n"((STAGE) * E_STAGEB + ((I) >> 2) * 4096) : "memory")
+// fragment i = (k-step i >> 1, d tile i & 1) of V set SET: two transposed 8-byte reads into the halves of a[..]
+#define E_READ_V(SET, I, STAGE) asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%5\n\tds_read_b64_tr_b16 a[%3:%4], %0 offset:%6" :: "v"(vaddr[(I) & 1]), \
+                                             "n"(A_VF + (SET) * 32 + (I) * 4), "n"(A_VF + (SET) * 32 + (I) * 4 + 1), "n"(A_VF + (SET) * 32 + (I) * 4 + 2), "n"(A_VF + (SET) * 32 + (I) * 4 + 3), \
+                                             "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048), "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048 + 512) : "memory")
 
-    // one key tile; the loop is unrolled four times so that the ring stage (t & 3) is a compile-time constant and PAR = t & 1 names the
-    // fragment sets: set PAR holds K(t) / V(t-1), set PAR ^ 1 receives K(t+1) / V(t).  Every MFMA gap is pinned by a scheduling fence:
-    // [MFMA] [2 v_exp, 2 v_add, 1 v_cvt_pk] [<= 3 LDS reads].
-    auto iter = [&](const int t, auto idx_tag) __attribute__((always_inline)) {
-        constexpr int IDX = decltype(idx_tag)::value;
-        constexpr int PAR = IDX & 1, NXT = PAR ^ 1;
-        // tile t+1 must have landed before its K fragments are read in slot 1; tile t+2 may stay in flight (4 DMA instructions)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        E_BARRIER();
-        if constexpr (!(VAR & 2) && !(VAR & 8)) dma_clamped(t + 3);   // stage (t+3)&3 = (t-1)&3: last read (V(t-1)) before the barrier above
-        E_FENCE();
-        // ---- slot 1: S'_b(t), O_b += V(t-1).P_b(t-1)  ||  softmax a(t)  ||  fragment reads K(t+1), V(t) into the other set ----
-        float ps = 0.f, dsh = 0.f;
-        static_for<0, 16>([&](auto it) {
-            constexpr int i = decltype(it)::value;
-            (void)&sb; (void)&cb; (void)&pkb; (void)&kaddr; (void)&vaddr;
-            E_SLOT_MFMA(i, sb, PAR, A_QB, cb, A_OB, PAR, pkb);
-            soft2(i, sa, pka, ps);
-            if constexpr (i < 8) { E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1)); E_READ_V(NXT, i, IDX); }
-            E_FENCE();
-        });
-        soft_tail(pka, ps);
-        if (__any(!(ps <= E_LAG_LIMIT))) ps = rebase(std::integral_constant<int, A_OA>{}, sa, pka, ca, ml_a, l_a, dsh);
-        if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sa, dsh); }
-        l_a += ps;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments read in slot 1 are in their registers
-        E_FENCE();
-        // ---- slot 2: S'_a(t+1), O_a += V(t).P_a(t)  ||  softmax b(t) ----
-        ps = 0.f; dsh = 0.f;
-        static_for<0, 16>([&](auto it) {
-            constexpr int i = decltype(it)::value;
-            (void)&sa; (void)&ca; (void)&pka;
-            E_SLOT_MFMA(i, sa, NXT, A_QA, ca, A_OA, NXT, pka);
-            soft2(i, sb, pkb, ps);
-            if constexpr ((VAR & 2) && !(VAR & 8) && (i & 3) == 2) dma_piece(t + 3, i >> 2);   // gaps 2, 6, 10, 14
-            E_FENCE();
-        });
-        soft_tail(pkb, ps);
-        if (__any(!(ps <= E_LAG_LIMIT))) ps = rebase(std::integral_constant<int, A_OB>{}, sb, pkb, cb, ml_b, l_b, dsh);
-        if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sb, dsh); }
-        l_b += ps;
-        E_FENCE();
+// everything a block (query tile, head, clip) needs, wave-uniform
+struct EncBlk {
+    int q0, Tq, klen, nt, h;
+    long long o_off;
+    const char* qb;
+    v4i_t krsrc, vrsrc;
+};
+
+__global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int ldkv2 = (int)(p.ld_kv * 2);
+    const int lds_base = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
+
+    // block v -> (query tile, head, clip): blocks v and v + 8 share an XCD (round-robin dispatch; the grid is a multiple of 8, so a
+    // persistent workgroup keeps its residue), and with v = xcd + 8 (xtile + n_qt * head_group), head = 8 head_group + xcd, the query tiles
+    // of one (clip, head) run at the same time on ONE XCD: its K / V is fetched from HBM once.  Head-major order when heads * clips % 8 != 0.
+    const int nh = p.n_h * p.B;
+    auto setup = [&](int v, EncBlk& k) -> bool {
+        int xt, hb;
+        if ((nh & 7) == 0) {
+            const int xcd = v & 7, r = v >> 3;
+            xt = r % p.n_qt;
+            hb = (r / p.n_qt) * 8 + xcd;
+        } else {
+            xt = v % p.n_qt;
+            hb = v / p.n_qt;
+        }
+        const int b = hb / p.n_h;
+        k.h = hb % p.n_h;
+        k.q0 = xt * E_QT;
+        long long q_off = (long long)b * p.q_bs, kv_off = (long long)b * p.kv_bs;
+        k.o_off = (long long)b * p.o_bs;
+        k.Tq = p.Tq;
+        k.klen = p.Tk;
+        if (p.key_len) { const int kl = p.key_len[b]; k.klen = kl < k.klen ? kl : k.klen; }
+        if (p.row_off) {
+            const long long r = p.row_off[b];
+            q_off = r * p.ld_q; kv_off = r * p.ld_kv; k.o_off = r * p.ld_o;
+            k.Tq = p.key_len[b];
+        }
+        if (k.q0 >= k.Tq) return false;               // packed batches: query tile past this clip
+        k.klen = k.klen > 0 ? k.klen : 0;
+        k.nt = (k.klen + E_KT - 1) / E_KT;
+        k.qb = p.q + (q_off + (long long)k.h * p.q_hs) * 2;
+        const unsigned long long ka = (unsigned long long)(p.k + (kv_off + (long long)k.h * p.kv_hs) * 2);
+        const unsigned long long va = (unsigned long long)(p.v + (kv_off + (long long)k.h * p.kv_hs) * 2);
+        // K rows past klen re-read the last live row (their scores equal the last live key's: finite, and removed from the row sums);
+        // V rows past klen are OUT OF RANGE of the V descriptor and arrive as zeros, so those keys add nothing to O
+        k.krsrc = v4i_t{__builtin_amdgcn_readfirstlane((int)(ka & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)((ka >> 32) & 0xffffu)), 0x7fffffff, 0x00020000};
+        k.vrsrc = v4i_t{__builtin_amdgcn_readfirstlane((int)(va & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)((va >> 32) & 0xffffu)),
+                        __builtin_amdgcn_readfirstlane((k.klen > 0 ? (k.klen - 1) * ldkv2 : 0) + E_ROWB), 0x00020000};
+        return true;
     };
-    for (int t = 0; t < nt; t += 4) {
-        iter(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nt) iter(t + 1, std::integral_constant<int, 1>{});
-        if (t + 2 < nt) iter(t + 2, std::integral_constant<int, 2>{});
-        if (t + 3 < nt) iter(t + 3, std::integral_constant<int, 3>{});
-    }
-    // drain: O_b += V(nt-1) . P_b(nt-1); V(nt-1) sits in the fragment set the LAST iteration filled (set PAR ^ 1 of t = nt - 1)
-    if (nt & 1) {
-        static_for<8, 16>([&](auto it) { constexpr int i = decltype(it)::value; (void)&sb; (void)&cb; (void)&pkb; E_SLOT_MFMA(i, sb, 0, A_QB, cb, A_OB, 1, pkb); });
-    } else {
-        static_for<8, 16>([&](auto it) { constexpr int i = decltype(it)::value; (void)&sb; (void)&cb; (void)&pkb; E_SLOT_MFMA(i, sb, 0, A_QB, cb, A_OB, 0, pkb); });
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // no LDS-DMA may outlive the K / V ring (it becomes the O staging
-    E_BARRIER();                                                                  // area); the last MFMA results are readable
+    // next block of this workgroup that has work, or -1
+    auto next_valid = [&](int v, EncBlk& k) -> int {
+        for (; v < p.n_blk; v += (int)gridDim.x)
+            if (setup(v, k)) return v;
+        return -1;
+    };
 
-    // ---- normalise, stage O through LDS, store whole rows.  O^T register e of d-tile dt is d = dt*32 + (e&3) + 8*(e>>2) + 4*fh of query
-    //      (lane & 31): the lane writes 4 consecutive d (8 bytes) at [query][d]; rows are 128 B + 16 B pad (conflict-free 8-byte stores) ----
-    const float la = l_a + __shfl_xor(l_a, 32, 64), lb = l_b + __shfl_xor(l_b, 32, 64);
-    const float ia = la > 0.f ? 1.0f / la : 0.f, ib = lb > 0.f ? 1.0f / lb : 0.f;
-    constexpr int OROW = 144;
-    char* ost = smem + wave * (64 * OROW);
-    static_for<0, 16>([&](auto it) {
-        constexpr int i = decltype(it)::value;                   // (block, d tile, group of 4 registers)
-        constexpr int blk = i >> 3, dt = (i >> 2) & 1, g = i & 3;
-        float o0, o1, o2, o3;
-        E_ACC_READ(o0, blk * 32 + dt * 16 + 4 * g);
-        E_ACC_READ(o1, blk * 32 + dt * 16 + 4 * g + 1);
-        E_ACC_READ(o2, blk * 32 + dt * 16 + 4 * g + 2);
-        E_ACC_READ(o3, blk * 32 + dt * 16 + 4 * g + 3);
-        const float inv = blk ? ib : ia;
-        const uint32_t w0 = e_cvt_pk(o0 * inv, o1 * inv), w1 = e_cvt_pk(o2 * inv, o3 * inv);
-        const int d = dt * 32 + 8 * g + 4 * fh;
-        *reinterpret_cast<uint2*>(ost + (blk * 32 + fr) * OROW + d * 2) = uint2{w0, w1};
-    });
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's own stores (its rows are private to it)
-    __builtin_amdgcn_wave_barrier();
+    // ---- LDS-DMA (buffer_load_dwordx4 ... lds) as INLINE ASM: hipcc's waitcnt pass drains every LDS-DMA it knows about (vmcnt(0)) in
+    //      front of LDS reads; issued from asm the stream is invisible to it and stays in flight behind the counted vmcnt of the tile loop
+    //      (cdna guide 5.7).  A wave-instruction fills 8 LDS rows of 128 B; lane (lrow, slot) writes slot `slot` of row r0 + lrow with
+    //      SOURCE chunk slot ^ swz(row) (linear image, swizzle on the source address).  Wave w owns rows 16 w .. 16 w + 15 of every tile. ----
+    auto dma16 = [&](const v4i_t& rsrc, int voff, int lds_addr) {
+#ifdef E_DMA_KEEP_M0
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+#else
+        // M0 is written and consumed inside the one statement and not restored: nothing hipcc emits in this kernel reads M0 (gfx950 LDS
+        // instructions do not need it; there is no compiler-issued LDS-DMA, s_sendmsg or v_movrel here -- checked in the .s)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+#endif
+    };
+    auto dma_tile = [&](const EncBlk& k, int t) {
+        const int ks = __builtin_amdgcn_readfirstlane(lds_base + (t & (E_NST - 1)) * E_STAGEB + wave * 2048);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = i * 8 + (lane >> 3), c = lane & 7;
-        const int qrow = q0 + wave * 64 + r;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(ost + r * OROW + c * 16);
-        if (qrow < Tq) {
-            __bf16* op = reinterpret_cast<__bf16*>(p.o) + o_off + (long long)qrow * p.ld_o + (long long)h * p.o_hs;
-            *reinterpret_cast<u32x4*>(op + c * 8) = val;
+        for (int u = 0; u < 2; ++u) {
+            const int row = wave * 16 + u * 8 + lrow;
+            const int key = t * E_KT + row;
+            const int keyc = key < k.klen ? key : k.klen - 1;
+            dma16(k.krsrc, keyc * ldkv2 + (lslot ^ ((row >> 1) & 7)) * 16, ks + u * 1024);                    // rswz<128>
+            dma16(k.vrsrc, key * ldkv2 + (lslot ^ (((row >> 1) & 1) << 2)) * 16, ks + E_TILEB + u * 1024);    // vtrswz<128>
+        }
+    };
+    // Q rows of a block: by LDS-DMA as well (8 instructions per wave, its own 64 rows; K's row swizzle).  A register-destination load
+    // would be counted by hipcc, which -- blind to the asm DMA stream -- waits vmcnt(0) for it at the next block's start: every tile in
+    // flight AND the previous block's O stores (measured: the persistent form was 6 % SLOWER than one workgroup per block that way).
+    auto dma_q = [&](const EncBlk& k) {
+        const unsigned long long qa_ = (unsigned long long)k.qb;
+        const v4i_t qrsrc = {__builtin_amdgcn_readfirstlane((int)(qa_ & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)((qa_ >> 32) & 0xffffu)), 0x7fffffff, 0x00020000};
+        const int qs = __builtin_amdgcn_readfirstlane(lds_base + E_QOFF + wave * 64 * E_ROWB);
+        const int ldq2 = (int)(p.ld_q * 2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = wave * 64 + u * 8 + lrow;                  // row of the workgroup's Q tile
+            int qrow = k.q0 + row;
+            qrow = qrow < k.Tq ? qrow : k.Tq - 1;
+            dma16(qrsrc, qrow * ldq2 + (lslot ^ ((row >> 1) & 7)) * 16, qs + u * 1024);
+        }
+    };
+    auto prefetch_tiles = [&](const EncBlk& k) {
+        if (k.nt > 0) dma_tile(k, 0);
+        if (k.nt > 1) dma_tile(k, 1);
+        if (k.nt > 2) dma_tile(k, 2);
+    };
+
+    // fragment read addresses: lane part in a VGPR, (ring stage, sub-tile, k-step) part in the instruction's 16-bit offset
+    const int krow0 = e_swap23(fr);
+    int kaddr[4];
+#pragma unroll
+    for (int dc = 0; dc < 4; ++dc) kaddr[dc] = lds_base + krow0 * E_ROWB + (((dc * 2 + fh) ^ ((krow0 >> 1) & 7)) << 4);   // sub-tile 1: + 32 rows = + 4096
+    int qaddr[4];
+#pragma unroll
+    for (int dc = 0; dc < 4; ++dc) qaddr[dc] = lds_base + E_QOFF + (wave * 64 + fr) * E_ROWB + (((dc * 2 + fh) ^ ((fr >> 1) & 7)) << 4);   // block b: + 32 rows
+    int vaddr[2];
+    {
+        const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + gsel * 16 + tp * 4;
+            const int key0 = fh * 8 + tq;                       // k-step s: + 16 rows = + 2048; second half: + 4 rows = + 512 (same swizzle)
+            vaddr[dt] = lds_base + E_TILEB + key0 * E_ROWB + (((col >> 3) ^ (((key0 >> 1) & 1) << 2)) << 4) + (col & 7) * 2;
         }
     }
+
+    EncBlk cur, nxt;
+    int v = next_valid((int)blockIdx.x, cur);
+    if (v < 0) return;                                           // workgroup-uniform, before any barrier
+    dma_q(cur);
+    prefetch_tiles(cur);
+    {   // V fragment sets = 0 once: the first slot of every block multiplies "V(-1)" (whatever the sets hold: finite) by P_b(-1) = 0
+        const uint32_t zero = 0u;
+        static_for<0, 64>([&](auto it) { const uint32_t z = zero; E_ACC_WRITE(A_VF + decltype(it)::value, z); });
+    }
+
+    for (;;) {
+        const int nt = cur.nt, klen = cur.klen;
+        // ---- block start: O = 0 ----
+        {
+            const uint32_t zero = 0u;
+            static_for<0, 64>([&](auto it) { const uint32_t z = zero; E_ACC_WRITE(A_OA + decltype(it)::value, z); });
+        }
+        E_FENCE();
+
+        f32x16 sa[2], sb[2];                    // S'^T [key sub-tile]                            (VGPR)
+        f32x16 ca, cb;                          // C input of each chain: -m_lag                  (VGPR)
+        u32x4 pka[4], pkb[4];                   // P as packed bf16: the B operand of PV k-step s (VGPR)
+        float ml_a = 0.f, ml_b = 0.f, l_a = 0.f, l_b = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ca[e] = 0.f; cb[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pka[i] = u32x4{0, 0, 0, 0}; pkb[i] = u32x4{0, 0, 0, 0}; }
+
+        // the two scores of MFMA gap i of a slot: P = exp2(S'), row-sum partial, packed bf16.  pk[s][j] holds registers 8 (s & 1) + 2 j, + 1
+        // of sub-tile s >> 1, i.e. pk[s] is the 8 keys of PV k-step s.
+        // (the row sum runs on FOUR independent partial sums: one chain of 32 dependent v_add_f32 per slot stalled the wave's in-order issue --
+        //  and with it the next MFMA -- behind every add's latency: 40 us of a 430-us launch)
+        auto soft2 = [&](const int i, const f32x16 (&s)[2], u32x4 (&pk)[4], float (&psum)[4]) __attribute__((always_inline)) {
+            const int ks = i >> 3, e = 2 * (i & 7);
+#if defined(E_TIMING_NOEXP)      /* TIMING EXPERIMENTS ONLY (wrong results) */
+            const float p0 = s[ks][e] * 0.5f, p1 = s[ks][e + 1] * 0.5f;
+#else
+            const float p0 = __builtin_amdgcn_exp2f(s[ks][e]), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1]);
+#endif
+#if !defined(E_TIMING_NOADD)
+            psum[(2 * i) & 3] += p0;
+            psum[(2 * i + 1) & 3] += p1;
+#endif
+#if defined(E_TIMING_NOCVT)
+            uint32_t w = __builtin_bit_cast(uint32_t, p0) ^ __builtin_bit_cast(uint32_t, p1);
+#else
+            uint32_t w = e_cvt_pk(p0, p1);
+#endif
+            asm volatile("" : "+v"(w));        // pinned here: the rare path overwrites P, and hipcc would sink the slot's 16 v_cvt_pk below its branch
+            pk[ks * 2 + ((i & 7) >> 2)][i & 3] = w;
+        };
+        // the rare path: raise the lag of one query block (O at a[OBASE .. OBASE + 31]) to the true maximum of this tile and redo its P
+        auto rebase = [&](auto obase_tag, const f32x16 (&s)[2], u32x4 (&pk)[4], f32x16& c, float& ml, float& l, float& d_out) -> float {
+            constexpr int OBASE = decltype(obase_tag)::value;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[ks][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float d = mx > 0.f ? mx : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l *= alpha;
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // the block's last O MFMA -> v_accvgpr_read (18 wait states)
+            static_for<0, 32>([&](auto it) {
+                constexpr int i = decltype(it)::value;
+                float x;
+                E_ACC_READ(x, OBASE + i);
+                x *= alpha;
+                E_ACC_WRITE(OBASE + i, x);
+            });
+            asm volatile("s_nop 1" ::: "memory");
+            ml += d;
+            d_out = d;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c[e] = -ml;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ks = i >> 3, e = 2 * (i & 7);
+                const float p0 = __builtin_amdgcn_exp2f(s[ks][e] - d), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1] - d);
+                psum += p0;
+                psum += p1;
+                pk[ks * 2 + ((i & 7) >> 2)][i & 3] = e_cvt_pk(p0, p1);
+            }
+            return psum;
+        };
+        // Last, partly filled tile: the keys past klen are copies of key klen - 1 (same K row -> bit-identical S'), with zero V rows.  They
+        // add nothing to O; their equal terms exp2(S'_last - d) are taken out of this lane's row-sum partial here (each half of a lane pair
+        // sums 32 of the tile's 64 keys: count the copies this half holds).  Once per query block per block, in a basic block of its own.
+        auto dup_sum = [&](const f32x16 (&s)[2], float d) -> float {
+            const int kk = (klen - 1) - (nt - 1) * E_KT;       // position of the last live key inside the last tile
+            float vv = 0.f;
+            int mine = 0, cnt = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = ks * 32 + e_swap23(mfma32_row(e, lane));
+                    vv = key == kk ? s[ks][e] : vv;
+                    mine |= key == kk ? 1 : 0;
+                    cnt += key > kk ? 1 : 0;
+                }
+            const float vo = __shfl_xor(vv, 32, 64);
+            const float sl = mine ? vv : vo;                   // the last live key sits in exactly one half of the pair
+            return (float)cnt * __builtin_amdgcn_exp2f(sl - d);
+        };
+        const bool has_edge = (klen % E_KT) != 0;
+
+        if (nt > 0) {
+            // ---- Q and tile 0 have landed?  FIFO of this wave: [Q rows (8)][tiles 0..2 of this block][0..8 O stores of the previous block].  The
+            //      count may only assume ops that are CERTAINLY younger than tile 0: tiles 1 and 2 (the stores are predicated per row and
+            //      may not exist; when they do, this merely waits for some of them as well) ----
+            if (nt >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            E_BARRIER();                                               // ... and everybody's
+            // Q fragments (B operand of S'^T): row = this lane's query, 16-byte chunk 2 dc + fh -> a[64:95]
+            static_for<0, 8>([&](auto it) {
+                constexpr int i = decltype(it)::value;                 // (block i >> 2, k-step i & 3)
+                (void)&qaddr;
+                asm volatile("ds_read_b128 a[%1:%2], %0 offset:%3" :: "v"(qaddr[i & 3]), "n"(A_QA + i * 4), "n"(A_QA + i * 4 + 3), "n"((i >> 2) * 32 * E_ROWB) : "memory");
+            });
+            static_for<0, 8>([&](auto it) { constexpr int i = decltype(it)::value; (void)&kaddr; E_READ_K(0, i, 0); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            E_FENCE();
+            // the true row maxima of tile 0 become the lags; then S'_a(0)
+            E_CHAINS(sa, 0, A_QA, ca);
+            E_CHAINS(sb, 0, A_QB, cb);
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // MFMA results -> VALU readers (18 wait states for a 16-pass MFMA)
+            E_FENCE();
+            float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { ma = fmaxf(ma, sa[ks][e]); mb = fmaxf(mb, sb[ks][e]); }
+            ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
+            mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+            ml_a = ma; ml_b = mb;                                  // finite: every key row of tile 0 is a live row (copies included)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ca[e] = -ml_a; cb[e] = -ml_b; }
+            E_FENCE();
+            E_CHAINS(sa, 0, A_QA, ca);
+
+            // one key tile; the loop is unrolled four times so that the ring stage (t & 3) is a compile-time constant and PAR = t & 1 names
+            // the fragment sets: set PAR holds K(t) / V(t-1), set PAR ^ 1 receives K(t+1) / V(t)
+            auto iter = [&](const int t, auto idx_tag) __attribute__((always_inline)) {
+                constexpr int IDX = decltype(idx_tag)::value;
+                constexpr int PAR = IDX & 1, NXT = PAR ^ 1;
+                // tile t+1 must have landed before its K fragments are read in slot 1; tile t+2 (4 DMA instructions) may stay in flight
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                E_BARRIER();
+                if (t + 3 < nt) dma_tile(cur, t + 3);          // stage (t+3)&3 = (t-1)&3: last read (V(t-1)) before the barrier above
+                E_FENCE();
+                // ---- slot 1 ----
+                float ps4[4] = {0.f, 0.f, 0.f, 0.f}, dsh = 0.f;
+                static_for<0, 16>([&](auto it) {
+                    constexpr int i = decltype(it)::value;
+                    (void)&sb; (void)&cb; (void)&pkb; (void)&kaddr; (void)&vaddr;
+                    E_SLOT_MFMA(i, sb, PAR, A_QB, cb, A_OB, PAR, pkb);
+                    soft2(i, sa, pka, ps4);
+                    if constexpr (i < 8) { E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1)); E_READ_V(NXT, i, IDX); }
+                    E_FENCE();
+                });
+                float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OA>{}, sa, pka, ca, ml_a, l_a, dsh);
+                if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sa, dsh); }
+                l_a += ps;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments read in slot 1 are in their registers
+                E_FENCE();
+                // ---- slot 2 ----
+                ps4[0] = ps4[1] = ps4[2] = ps4[3] = 0.f; dsh = 0.f;
+                static_for<0, 16>([&](auto it) {
+                    constexpr int i = decltype(it)::value;
+                    (void)&sa; (void)&ca; (void)&pka;
+                    E_SLOT_MFMA(i, sa, NXT, A_QA, ca, A_OA, NXT, pka);
+                    soft2(i, sb, pkb, ps4);
+                    E_FENCE();
+                });
+                ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OB>{}, sb, pkb, cb, ml_b, l_b, dsh);
+                if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sb, dsh); }
+                l_b += ps;
+                E_FENCE();
+            };
+            for (int t = 0; t < nt; t += 4) {
+                iter(t, std::integral_constant<int, 0>{});
+                if (t + 1 < nt) iter(t + 1, std::integral_constant<int, 1>{});
+                if (t + 2 < nt) iter(t + 2, std::integral_constant<int, 2>{});
+                if (t + 3 < nt) iter(t + 3, std::integral_constant<int, 3>{});
+            }
+            // drain: O_b += V(nt-1) . P_b(nt-1); V(nt-1) sits in the fragment set the LAST iteration filled (set PAR ^ 1 of t = nt - 1)
+            if (nt & 1) {
+                static_for<8, 16>([&](auto it) { constexpr int i = decltype(it)::value; (void)&sb; (void)&cb; (void)&pkb; E_SLOT_MFMA(i, sb, 0, A_QB, cb, A_OB, 1, pkb); });
+            } else {
+                static_for<8, 16>([&](auto it) { constexpr int i = decltype(it)::value; (void)&sb; (void)&cb; (void)&pkb; E_SLOT_MFMA(i, sb, 0, A_QB, cb, A_OB, 0, pkb); });
+            }
+            E_BARRIER();                                              // every wave is done reading the ring: the next block's tiles may land
+        }
+
+        // ---- the next block's Q rows and first tiles are requested BEFORE this block's epilogue (their latency hides behind it) ----
+        const long long o_off = cur.o_off;
+        const int q0 = cur.q0, Tq = cur.Tq, hh = cur.h;
+        v = next_valid(v + (int)gridDim.x, nxt);
+        if (v >= 0) {
+            dma_q(nxt);
+            prefetch_tiles(nxt);
+        }
+        E_FENCE();
+
+        // ---- epilogue: normalise, stage O through this wave's private LDS area, store whole rows.  O^T register e of d-tile dt is
+        //      d = dt*32 + (e&3) + 8*(e>>2) + 4*fh of query (lane & 31): the lane writes 4 consecutive d (8 bytes) at [query][d] ----
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");            // the last MFMA results are readable
+        const float la = l_a + __shfl_xor(l_a, 32, 64), lb = l_b + __shfl_xor(l_b, 32, 64);
+        const float ia = la > 0.f ? 1.0f / la : 0.f, ib = lb > 0.f ? 1.0f / lb : 0.f;
+        char* ost = smem + E_RING + wave * (64 * E_OROW);
+        static_for<0, 16>([&](auto it) {
+            constexpr int i = decltype(it)::value;                   // (block, d tile, group of 4 registers)
+            constexpr int blk = i >> 3, dt = (i >> 2) & 1, g = i & 3;
+            float o0, o1, o2, o3;
+            E_ACC_READ(o0, blk * 32 + dt * 16 + 4 * g);
+            E_ACC_READ(o1, blk * 32 + dt * 16 + 4 * g + 1);
+            E_ACC_READ(o2, blk * 32 + dt * 16 + 4 * g + 2);
+            E_ACC_READ(o3, blk * 32 + dt * 16 + 4 * g + 3);
+            const float inv = blk ? ib : ia;
+            const uint32_t w0 = e_cvt_pk(o0 * inv, o1 * inv), w1 = e_cvt_pk(o2 * inv, o3 * inv);
+            const int d = dt * 32 + 8 * g + 4 * fh;
+            *reinterpret_cast<uint2*>(ost + (blk * 32 + fr) * E_OROW + d * 2) = uint2{w0, w1};
+        });
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's own stores (its rows are private to it)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + (lane >> 3), c = lane & 7;
+            const int qrow = q0 + wave * 64 + r;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(ost + r * E_OROW + c * 16);
+            if (qrow < Tq) {
+                __bf16* op = reinterpret_cast<__bf16*>(p.o) + o_off + (long long)qrow * p.ld_o + (long long)hh * p.o_hs;
+                *reinterpret_cast<u32x4*>(op + c * 8) = val;
+            }
+        }
+        if (v < 0) break;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -506,28 +525,17 @@ bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s) {
     p.q_bs = a->q_batch_stride; p.kv_bs = a->kv_batch_stride; p.o_bs = a->o_batch_stride;
     p.q_hs = a->q_head_stride; p.kv_hs = a->kv_head_stride; p.o_hs = a->o_head_stride > 0 ? a->o_head_stride : a->hd;
     p.n_qt = cdiv(a->Tq, E_QT);
-    if ((long long)p.n_qt * a->n_q * a->B >= (1ll << 31)) return false;
+    const long long nblk = (long long)p.n_qt * a->n_q * a->B;
+    if (nblk >= (1ll << 31)) return false;
+    p.n_blk = (int)nblk;
     static unsigned long long attr_done = 0;
-    if (afhip_first_use_on_device(&attr_done)) {
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-    }
-    const dim3 grid((unsigned)(p.n_qt * a->n_q * a->B));
-    const char* ev = getenv("AFHIP_ENC64_VAR");          // read per call: one process can A/B the variants
-    const int var = ev ? atoi(ev) : 0;
-    switch (var) {
-        case 1: hipLaunchKernelGGL(attn_enc64_kernel<1>, grid, dim3(256), E_LDS, s, p); break;
-        case 2: hipLaunchKernelGGL(attn_enc64_kernel<2>, grid, dim3(256), E_LDS, s, p); break;
-        case 3: hipLaunchKernelGGL(attn_enc64_kernel<3>, grid, dim3(256), E_LDS, s, p); break;
-        case 4: hipLaunchKernelGGL(attn_enc64_kernel<4>, grid, dim3(256), E_LDS, s, p); break;
-        case 8: hipLaunchKernelGGL(attn_enc64_kernel<8>, grid, dim3(256), E_LDS, s, p); break;
-        case 12: hipLaunchKernelGGL(attn_enc64_kernel<12>, grid, dim3(256), E_LDS, s, p); break;
-        default: hipLaunchKernelGGL(attn_enc64_kernel<0>, grid, dim3(256), E_LDS, s, p); break;
-    }
+    if (afhip_first_use_on_device(&attr_done))
+        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
+    // persistent: one workgroup per CU (the whole register file per wave), a multiple of 8 so that a workgroup keeps its XCD residue
+    int ncu = afhip_cu_count();
+    ncu = ncu >= 8 ? (ncu / 8) * 8 : ncu;
+    int grid = nblk < ncu ? (int)nblk : ncu;
+    { const char* e = getenv("AFHIP_ENC64_ONE_BLOCK_PER_WG"); if (e && e[0] == '1') grid = (int)nblk; }   // A/B switch, read per call
+    hipLaunchKernelGGL(attn_enc64_kernel, dim3((unsigned)grid), dim3(256), E_LDS, s, p);
     return true;
 }
