@@ -330,8 +330,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[ks][e]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));         // the two lanes of a query agree
-                // raise the lag to this tile's true maximum (first tile: SET it, O and l are still empty)
-                float d = (first || mx > 0.f) ? mx : 0.f;
+                // raise the lag to this tile's true maximum (first tile: SET it, O and l are still empty) -- only for the queries whose OWN
+                // partial sum tripped the limit: a query's bits must not depend on which other queries share its wave
+                const int own = !(psum <= LAG_SUM_LIMIT) ? 1 : 0;
+                const bool trig = first || (own | __shfl_xor(own, 32, 64)) != 0;
+                float d = (trig && (first || mx > 0.f)) ? mx : 0.f;
                 d = (d == -INFINITY) ? 0.f : d;
                 if (!first) {
                     const float alpha = __builtin_amdgcn_exp2f(-d);

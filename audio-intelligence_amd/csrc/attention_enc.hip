@@ -312,15 +312,19 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
             pk[ks * 2 + ((i & 7) >> 2)][i & 3] = w;
         };
         // the rare path: raise the lag of one query block (O at a[OBASE .. OBASE + 31]) to the true maximum of this tile and redo its P
-        auto rebase = [&](auto obase_tag, const f32x16 (&s)[2], u32x4 (&pk)[4], f32x16& c, float& ml, float& l, float& d_out) -> float {
+        // Only the queries whose OWN partial sum tripped the limit (either half of the lane pair) move their lag: a query's bits must not
+        // depend on which other queries share its wave (packed and padded batches put different neighbours there).
+        auto rebase = [&](auto obase_tag, const f32x16 (&s)[2], u32x4 (&pk)[4], f32x16& c, float& ml, float& l, float& d_out, float ps_own) -> float {
             constexpr int OBASE = decltype(obase_tag)::value;
+            const int own = !(ps_own <= E_LAG_LIMIT) ? 1 : 0;
+            const bool trig = (own | __shfl_xor(own, 32, 64)) != 0;
             float mx = -INFINITY;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[ks][e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float d = mx > 0.f ? mx : 0.f;
+            const float d = (trig && mx > 0.f) ? mx : 0.f;
             const float alpha = __builtin_amdgcn_exp2f(-d);
             l *= alpha;
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // the block's last O MFMA -> v_accvgpr_read (18 wait states)
@@ -336,16 +340,18 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
             d_out = d;
 #pragma unroll
             for (int e = 0; e < 16; ++e) c[e] = -ml;
-            float psum = 0.f;
+            // same four partial sums, same order as the fast path: a lane whose own maximum did not move (d = 0) must get the bits it
+            // would have got without its wave-mates' rebase (packed and padded batches put different queries side by side in a wave)
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ks = i >> 3, e = 2 * (i & 7);
                 const float p0 = __builtin_amdgcn_exp2f(s[ks][e] - d), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1] - d);
-                psum += p0;
-                psum += p1;
+                ps4[(2 * i) & 3] += p0;
+                ps4[(2 * i + 1) & 3] += p1;
                 pk[ks * 2 + ((i & 7) >> 2)][i & 3] = e_cvt_pk(p0, p1);
             }
-            return psum;
+            return (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         };
         // Last, partly filled tile: the keys past klen are copies of key klen - 1 (same K row -> bit-identical S'), with zero V rows.  They
         // add nothing to O; their equal terms exp2(S'_last - d) are taken out of this lane's row-sum partial here (each half of a lane pair
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                     E_FENCE();
                 });
                 float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OA>{}, sa, pka, ca, ml_a, l_a, dsh);
+                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OA>{}, sa, pka, ca, ml_a, l_a, dsh, ps);
                 if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sa, dsh); }
                 l_a += ps;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments read in slot 1 are in their registers
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                     E_FENCE();
                 });
                 ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OB>{}, sb, pkb, cb, ml_b, l_b, dsh);
+                if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OB>{}, sb, pkb, cb, ml_b, l_b, dsh, ps);
                 if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sb, dsh); }
                 l_b += ps;
                 E_FENCE();
