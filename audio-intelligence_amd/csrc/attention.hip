@@ -456,14 +456,34 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         if (wave == 0 && qrow < p.Tq) {
             const long long slot = (((long long)split * p.B + b) * p.n_q + hq) * 32 + fr;
             float* po = p.part_o + slot * HD;
+            if (p.ticket) {
+                // in-launch merge: the partials are stored WRITE-THROUGH (sc1: relaxed agent-scope 8-byte stores), so the producer needs no
+                // release fence (cdna guide, Guideline 16 R1) -- the L2 write-back of a release in each of the ~256 workgroups is what made
+                // the fenced form slower than a separate combine launch
+                typedef unsigned long long u64;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = dt * 32 + 8 * g + 4 * fh;
-                    *reinterpret_cast<f32x4*>(po + d) = f32x4{ot[dt][4 * g], ot[dt][4 * g + 1], ot[dt][4 * g + 2], ot[dt][4 * g + 3]};
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = dt * 32 + 8 * g + 4 * fh;
+                        const f32x2 lo = {ot[dt][4 * g], ot[dt][4 * g + 1]}, hi = {ot[dt][4 * g + 2], ot[dt][4 * g + 3]};
+                        __hip_atomic_store(reinterpret_cast<u64*>(po + d), __builtin_bit_cast(u64, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(reinterpret_cast<u64*>(po + d + 2), __builtin_bit_cast(u64, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                if (fh == 0) {
+                    const f32x2 ml = {m_i, l_tot};
+                    __hip_atomic_store(reinterpret_cast<u64*>(p.part_ml + slot * 2), __builtin_bit_cast(u64, ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            if (fh == 0) { p.part_ml[slot * 2] = m_i; p.part_ml[slot * 2 + 1] = l_tot; }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = dt * 32 + 8 * g + 4 * fh;
+                        *reinterpret_cast<f32x4*>(po + d) = f32x4{ot[dt][4 * g], ot[dt][4 * g + 1], ot[dt][4 * g + 2], ot[dt][4 * g + 3]};
+                    }
+                if (fh == 0) { p.part_ml[slot * 2] = m_i; p.part_ml[slot * 2 + 1] = l_tot; }
+            }
         }
         if (p.ticket == nullptr) return;
         const int n_live = p.seq_pos ? (tk_b + p.key_split - 1) / p.key_split : p.n_xt;
@@ -472,8 +492,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         __syncthreads();                                                   // ... and every wave's
         int* flag = reinterpret_cast<int*>(smem);                          // the K/V tiles are dead: their LDS carries the verdict
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // keep: ROCm 7.2 can drop the fence's own wait
+            // (no release fence: every partial byte went out as an sc1 store and every storing wave drained vmcnt before the barrier above)
             const int tk = __hip_atomic_fetch_add(p.ticket + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag[0] = (tk == n_live - 1) ? 1 : 0;
         }

@@ -41,7 +41,7 @@ EncWs carve(const afhip_encoder_weights* w, int B, char* base) {
     ws.qkv = take(rows * 3 * d * sz);
     ws.att = take(rows * d * sz);
     ws.part = (float*)take((d / 64 + 1) * rows * 2 * sizeof(float));
-    ws.stats = (float*)take(rows * 2 * sizeof(float));
+    ws.stats = (float*)take(rows * 4 * sizeof(float));   // [rows][2] (mean, rstd); the e4m3 mode keeps its [rows] activation scales in the first half and the statistics behind them
     ws.roff = (int32_t*)take(((size_t)B + 1) * sizeof(int32_t));
     ws.total = off;
     return ws;
@@ -170,9 +170,19 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
                 const char* e2 = getenv("AFHIP_FP8_FC2");
                 if (e2 && e2[0] == '1') mask |= 8;
             }
+            // q | k | v in bf16: the LayerNorm-folded GEMM over the raw stream when the folded weights exist (row statistics from the
+            // conv stem / the previous layer's bf16 fc2 epilogue, exactly as in the bf16 mode; q leaves prescaled for the encoder
+            // attention kernel), else an explicit LayerNorm + the plain GEMM
+            const bool qkv_fold = !(mask & 1) && !(mask & 8) && fold;
             if (mask & 1) {
                 if ((rc = afhip_quant_rows(h, d, w->ln1_w[l], w->ln1_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
                 if ((rc = gemm8(ws.ln, sc, w->qkv_w8[l], w->qkv_s8[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, 3 * d, 0, AFHIP_ACT_NONE, s))) return rc;
+            } else if (qkv_fold) {
+                float* st = ws.stats + (size_t)2 * rows;          // (mean, rstd) live behind the activation row scales (sc) in the stats buffer
+                if (l == 0 && (rc = afhip_row_stats(h, rows, d, 1e-5f, dt, st, s))) return rc;
+                if ((rc = gemm(h, w->qkv_wf[l], nullptr, nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+                               st, w->qkv_cs[l], w->qkv_bf[l], nullptr))) return rc;
+                a.q_prescaled = w->q_prescaled ? 1 : 0;
             } else {
                 if ((rc = afhip_layernorm(h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
                 if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
@@ -196,6 +206,12 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
             if (mask & 8) {
                 if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
                 if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;
+            } else if (qkv_fold) {
+                // bf16 fc2 with the row-statistics epilogue: the next layer's LayerNorm-folded q | k | v reads them
+                const bool last = l + 1 == w->n_layers;
+                if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], h, h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s, 0, 0, 0, 0,
+                               nullptr, nullptr, nullptr, last ? nullptr : ws.part))) return rc;
+                if (!last && (rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats + (size_t)2 * rows, s))) return rc;
             } else {
                 if ((rc = gemm(ws.big, w->fc2_w[l], w->fc2_b[l], h, h, rows, d, f, f, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
             }

@@ -7,9 +7,17 @@
 namespace {
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-#ifndef DECODE_IN_LAUNCH_MERGE
-#define DECODE_IN_LAUNCH_MERGE 0   /* 1: merge the decode attention's key-range partials by a last-arriver ticket instead of a second launch */
+// merge of the decode attention's key-range partials: by the last-arriving workgroup inside the attention launch (1) or by a second
+// launch (0).  AFHIP_DECODE_MERGE overrides at run time (A/B).
+#ifndef DECODE_IN_LAUNCH_MERGE_DEFAULT
+#define DECODE_IN_LAUNCH_MERGE_DEFAULT 0
 #endif
+static int decode_in_launch_merge() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AFHIP_DECODE_MERGE"); v = e ? (e[0] == '1') : DECODE_IN_LAUNCH_MERGE_DEFAULT; }
+    return v;
+}
+#define DECODE_IN_LAUNCH_MERGE decode_in_launch_merge()
 #ifndef DECODE_KEY_SPLIT
 #define DECODE_KEY_SPLIT 128   /* keys per workgroup of the split-context decode attention (multiple of 64); 256 / 128 / 64 measured 3.85 / 3.79 / 3.84 ms per 7B step */
 #endif

@@ -105,6 +105,7 @@ class _Backbone(nn.Module):
 
 
 from ..utils.quant import quantize_rows_e4m3 as _quantize_rows_e4m3  # noqa: E402
+from .. import torch_ops  # noqa: E402,F401  (registers torch.ops.afhip.*: the forwards below run through them)
 
 
 def pack_qwen2_weights(backbone: "_Backbone", lm_head_w: torch.Tensor, stream_emb_w: Optional[torch.Tensor], cfg: dict, n_stream: int,
@@ -169,7 +170,8 @@ def pack_qwen2_weights(backbone: "_Backbone", lm_head_w: torch.Tensor, stream_em
     fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
     cos, sin = P(fr.cos().to(dev)), P(fr.sin().to(dev))
     w.rope_cos, w.rope_sin, w.rope_max_pos = cos.data_ptr(), sin.data_ptr(), max_pos
-    return SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv)
+    from .. import torch_ops
+    return SimpleNamespace(w=w, keep=keep, arrays=arrays, max_pos=max_pos, hd=hd, nq=nq, nkv=nkv, blob=torch_ops.weights_blob(w))
 
 
 class ParallelLLM(nn.Module):
@@ -422,29 +424,35 @@ class ParallelLLM(nn.Module):
         cache.reserve(pos0 + T)
         pk = self.pack(cache.cap)
         x = input_embeds.to(self.dtype).contiguous()
-        hid = torch.empty_like(x)
         ws = self._workspace(B, T, cache.cap)
-        cs = cache.struct()
-        L.check(lib.afhip_llm_forward(C.byref(pk.w), L.ptr(x), B, T, pos0, C.byref(cs), L.ptr(hid), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        hid = torch.ops.afhip.llm_forward(pk.blob, x, pos0, cache.k, cache.v, ws)      # custom op over the opaque packed-weight blob (torch_ops.py)
         cache.length = pos0 + T
         return hid, cache
 
     @torch.no_grad()
-    def _step(self, input_ids=None, input_embeds=None, past_key_values=None, mask=None):
-        """lm/parallel.py:570-597 -> (logits [B,T,S,V], cache)."""
+    def _step(self, input_ids=None, input_embeds=None, past_key_values=None, mask=None, last_only: bool = False):
+        """lm/parallel.py:570-597 -> (logits [B,T,S,V] in the model dtype, cache).
+        `last_only=True` (not in the reference): logits of the LAST position only, [B,1,S,V] -- all a decoding caller slices
+        (lm/parallel.py:447).  The full form is produced in chunks of 64 rows through one f32 buffer, so a T = 790 prefill at the 7B
+        vocabulary peaks at the [B,T,8,V] result itself (2 GB in bf16) instead of an f32 copy (4 GB) next to it."""
         assert (input_ids is None) != (input_embeds is None), "Either input_ids or input_embeds should be None"
         lib = L.lib()
         if input_ids is not None:
             assert input_ids.size(2) == self.num_stream
             input_embeds = ops.embed_sum(input_ids.to(self.device), self.model.embed_tokens.weight)
         hid, cache = self._forward_hidden(input_embeds, past_key_values)
+        if last_only:
+            hid = hid[:, -1:].contiguous()
         B, T, H = hid.shape
         S, V = self.num_stream, self.lm_head.weight.shape[0]
-        logits = torch.empty((B, T, S, V), dtype=torch.float32, device=self.device)
-        need = B * T * S * H * hid.element_size() + 256
-        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hid), B * T, S, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
-        logits = logits.to(self.dtype)
+        rows = hid.reshape(B * T, H)
+        logits = torch.empty((B * T, S, V), dtype=self.dtype, device=self.device)
+        CH = 64
+        ws = torch.empty(min(CH, B * T) * S * H * hid.element_size() + 256, dtype=torch.uint8, device=self.device)
+        for r0 in range(0, B * T, CH):
+            n = min(CH, B * T - r0)
+            logits[r0:r0 + n].copy_(torch.ops.afhip.lm_head(self.pack().blob, rows[r0:r0 + n].contiguous(), S, ws))
+        logits = logits.view(B, T, S, V)
         if mask is not None:
             logits.masked_fill_(mask, float("-inf"))
         return logits, cache
@@ -456,10 +464,8 @@ class ParallelLLM(nn.Module):
         lib = L.lib()
         hidden = hidden.contiguous()
         n = hidden.shape[0]
-        logits = torch.empty((n, self.lm_head.weight.shape[0]), dtype=torch.float32, device=hidden.device)
         ws = torch.empty(n * hidden.shape[-1] * hidden.element_size() + 256, dtype=torch.uint8, device=hidden.device)
-        L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hidden), n, 1, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
-        return logits
+        return torch.ops.afhip.lm_head(self.pack().blob, hidden, 1, ws)[:, 0]
 
     @torch.no_grad()
     def _masked_pick(self, logits: torch.Tensor, iv: torch.Tensor) -> torch.Tensor:
@@ -548,16 +554,12 @@ class ParallelLLM(nn.Module):
         # arguments, so ONE captured hipGraph of a step serves every token
         seq_pos = torch.full((B,), T0, dtype=torch.int32, device=self.device)
         step_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
-        st = L.DecodeState()
-        st.prev_token, st.out_tokens, st.finished_at = prev.data_ptr(), out_tokens.data_ptr(), finished.data_ptr()
-        st.allowed, st.n_iv, st.eos_id, st.eot_id = iv.data_ptr(), iv.shape[0], self.eos_token_id, self.eot_token_id
-        st.seq_pos, st.step_counter = seq_pos.data_ptr(), step_counter.data_ptr()
         ws = self._workspace(B, 1, cache.cap)
-        cs = cache.struct()
         max_pos = T0 + max_step - 1                      # largest position this loop can append at
 
         def one_step():
-            L.check(lib.afhip_llm_decode_step(C.byref(pk.w), C.byref(cs), C.byref(st), B, max_pos, 0, L.ptr(ws), ws.numel(), L.stream_ptr()))
+            torch.ops.afhip.llm_decode_step(pk.blob, cache.k, cache.v, prev, out_tokens, finished, iv, self.eos_token_id, self.eot_token_id,
+                                            seq_pos, step_counter, max_pos, ws)
 
         # a capture costs a device synchronise + allocator housekeeping (~ms): only worth it for loops long enough to amortise it
         use_graph = os.environ.get("AFHIP_DECODE_GRAPH", "1") != "0" and max_step >= 16 and not torch.cuda.is_current_stream_capturing()
@@ -655,9 +657,8 @@ class ParallelLLM(nn.Module):
                     prev_token = prev_token.tile(2, 1, 1)
                 nrow = prev_token.shape[0]
                 hid, cache = self._forward_hidden(ops.embed_sum(prev_token, self.model.embed_tokens.weight), cache)
-                logits = torch.empty((nrow * S, V), dtype=torch.float32, device=device)
                 ws = torch.empty(nrow * S * H * hid.element_size() + 256, dtype=torch.uint8, device=device)
-                L.check(lib.afhip_lm_head(C.byref(self.pack().w), L.ptr(hid), nrow, S, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+                logits = torch.ops.afhip.lm_head(self.pack().blob, hid.reshape(nrow, H), S, ws).reshape(nrow * S, V)
                 cond, uncond = (logits[: nb * S], logits[nb * S:]) if cfg > 1 else (logits, None)
                 if temperature == 0:
                     idx, _, _, _ = self._topk_probs(cond, allowed, 1, 1.0, cfg_logits=uncond, cfg=cfg)

@@ -242,7 +242,8 @@ class AFWhisperEncoder(nn.Module):
             arrays[n] = L.ptr_array(lists[n])
             setattr(w, n, C.cast(arrays[n], L.c_void_pp))
         w.lnf_w, w.lnf_b = P(self.layer_norm.weight).data_ptr(), P(self.layer_norm.bias).data_ptr()
-        self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays)
+        from .. import torch_ops
+        self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays, blob=torch_ops.weights_blob(w))
         return self._packed
 
     def _workspace(self, B: int) -> torch.Tensor:
@@ -277,20 +278,14 @@ class AFWhisperEncoder(nn.Module):
         fl = None
         if feat_len is not None:
             fl = feat_len.to(device=self.device, dtype=torch.int32).contiguous()
-        out = torch.empty((B, cfg.max_source_positions // 2, cfg.d_model), dtype=self.dtype, device=self.device)
-        hid = None
-        if hidden_layer is not None:
-            hid = torch.empty((B, cfg.max_source_positions, cfg.d_model), dtype=self.dtype, device=self.device)
         ws = self._workspace(B)
+        # the forward itself is the custom op afhip::encoder_forward (torch_ops.py) over the opaque packed-weight blob
         if ragged:
             if feat_len is None or hidden_layer is not None:
                 raise ValueError("ragged=True needs feat_len and cannot return hidden states")
             fl_host = feat_len.detach().to(device="cpu", dtype=torch.int32).contiguous()
-            L.check(lib.afhip_encoder_forward_ragged(C.byref(pk.w), L.ptr(mel_btc), L.ptr(fl), fl_host.data_ptr(), B, L.ptr(out),
-                                                     L.ptr(ws), ws.numel(), L.stream_ptr()))
-            return out
-        L.check(lib.afhip_encoder_forward(C.byref(pk.w), L.ptr(mel_btc), L.ptr(fl), B, L.ptr(out), L.ptr(hid),
-                                          hidden_layer if hidden_layer is not None else -1, L.ptr(ws), ws.numel(), L.stream_ptr()))
+            return torch.ops.afhip.encoder_forward_ragged(pk.blob, mel_btc, fl, fl_host, ws)
+        out, hid = torch.ops.afhip.encoder_forward(pk.blob, mel_btc, fl, hidden_layer if hidden_layer is not None else -2, ws)
         return (out, hid) if hidden_layer is not None else out
 
     @torch.no_grad()

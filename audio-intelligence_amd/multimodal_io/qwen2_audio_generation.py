@@ -138,10 +138,8 @@ class Qwen2AudioForConditionalGeneration(nn.Module):
         lib = L.lib()
         hidden_rows = hidden_rows.contiguous()
         n = hidden_rows.shape[0]
-        logits = torch.empty((n, self.vocab_size), dtype=torch.float32, device=hidden_rows.device)
         ws = torch.empty(n * hidden_rows.shape[1] * hidden_rows.element_size() + 256, dtype=torch.uint8, device=hidden_rows.device)
-        L.check(lib.afhip_lm_head(C.byref(self.language_model.pack().w), L.ptr(hidden_rows), n, 1, L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
-        return logits
+        return torch.ops.afhip.lm_head(self.language_model.pack().blob, hidden_rows, 1, ws)[:, 0]
 
     def _encode_audio(self, input_features, feature_attention_mask):
         """modeling_whisper.py:1181-1207: per-clip key length from the feature mask, encoder, projector."""
@@ -182,10 +180,8 @@ class Qwen2AudioForConditionalGeneration(nn.Module):
             max_pos = c.kv.cap - 1
             pk = self.language_model.pack(c.kv.cap)
             x = inputs_embeds.reshape(B, -1).to(self.dtype).contiguous()
-            hid = torch.empty_like(x)
             ws = self._workspace(B, 1, c.kv.cap)
-            cs = c.kv.struct()
-            L.check(lib.afhip_llm_forward_ragged(C.byref(pk.w), L.ptr(x), B, L.ptr(c.seq_len), max_pos, C.byref(cs), L.ptr(hid), L.ptr(ws), ws.numel(), L.stream_ptr()))
+            hid = torch.ops.afhip.llm_forward_ragged(pk.blob, x, c.seq_len, max_pos, c.kv.k, c.kv.v, ws)
             c.seq_len += 1
             c.padded_len += 1
             c.compact_len += 1
@@ -238,10 +234,8 @@ class Qwen2AudioForConditionalGeneration(nn.Module):
         xc = torch.gather(inputs_embeds.to(self.dtype), 1, order[:, :Lmax, None].expand(B, Lmax, H)).contiguous()
         kv = self._new_kv(B, Lmax + max_new_tokens + 1)
         pk = self.language_model.pack(kv.cap)
-        hid = torch.empty_like(xc)
         ws = self._workspace(B, Lmax, kv.cap)
-        cs = kv.struct()
-        L.check(lib.afhip_llm_forward(C.byref(pk.w), L.ptr(xc), B, Lmax, 0, C.byref(cs), L.ptr(hid), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        hid = torch.ops.afhip.llm_forward(pk.blob, xc, 0, kv.k, kv.v, ws)
         kv.length = Lmax
         return hid, AF3Cache(kv, lens.to(torch.int32).contiguous(), Lp, Lmax), mask, attention_mask, labels, position_ids
 

@@ -2,8 +2,14 @@
 `afhip::` namespace -- the boundary wording of BASELINE's north star ("behind PyTorch-ROCm custom ops").  The ops are thin: the
 implementation of each is the ctypes call in ops.py (device pointers + the current HIP stream), so there is still exactly one native
 library and no second code path; what the registration adds is the dispatcher entry, schema checking and fake-tensor (meta) kernels,
-so the ops can be traced / shape-propagated (torch.compile, FakeTensorMode) without a GPU.  Stateful pieces (the encoder and LLM
-forwards, which take packed weight tables) stay methods of the drop-in classes.
+so the ops can be traced / shape-propagated (torch.compile, FakeTensorMode) without a GPU.
+
+The entry points that carry the time -- `afhip_encoder_forward(_ragged)`, `afhip_llm_forward(_ragged)`, `afhip_lm_head`,
+`afhip_llm_decode_step` -- are ops too, and the drop-in classes (AFWhisperEncoder.encode_btc, ParallelLLM._forward_hidden / _step /
+the greedy device loop, Qwen2AudioForConditionalGeneration) call THROUGH them: `torch.ops.afhip.encoder_forward(...)`.  Their packed
+weight table (`afhip_encoder_weights` / `afhip_llm_weights`: pointers to tensors the module keeps alive) travels as an OPAQUE uint8 CPU
+tensor that aliases the ctypes struct (`pack().blob`); KV caches, workspaces and loop state are ordinary tensors the schema marks
+as mutated.
 
     import audio_intelligence_amd.torch_ops          # registers torch.ops.afhip.*
     y = torch.ops.afhip.gemm(a, w, bias, 1, None)    # == ops.gemm(a, w, bias=bias, act=ACT_GELU)
@@ -24,6 +30,14 @@ _lib_def.define("attention_packed(Tensor qkv, int n_heads, Tensor? key_len, bool
 _lib_def.define("log_mel(Tensor wav, bool btc, ScalarType dtype) -> Tensor")
 _lib_def.define("quant_rows(Tensor x, int mode, Tensor? w, Tensor? b, float eps) -> (Tensor, Tensor)")
 _lib_def.define("gemm_fp8(Tensor aq, Tensor a_scale, Tensor wq, Tensor w_scale, Tensor? bias, int act, Tensor? residual) -> Tensor")
+# stateful entry points: `weights` = opaque uint8 CPU tensor aliasing the packed-weight struct
+_lib_def.define("encoder_forward(Tensor weights, Tensor mel_btc, Tensor? feat_len, int hidden_layer, Tensor(a!) workspace) -> (Tensor, Tensor)")
+_lib_def.define("encoder_forward_ragged(Tensor weights, Tensor mel_btc, Tensor feat_len, Tensor feat_len_host, Tensor(a!) workspace) -> Tensor")
+_lib_def.define("llm_forward(Tensor weights, Tensor x, int pos0, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor(c!) workspace) -> Tensor")
+_lib_def.define("llm_forward_ragged(Tensor weights, Tensor x, Tensor seq_pos, int max_pos, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor(c!) workspace) -> Tensor")
+_lib_def.define("lm_head(Tensor weights, Tensor hidden_rows, int n_stream, Tensor(a!) workspace) -> Tensor")
+_lib_def.define("llm_decode_step(Tensor weights, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor(c!) prev_token, Tensor(d!) out_tokens, Tensor(e!) finished_at, "
+                "Tensor allowed, int eos_id, int eot_id, Tensor(f!) seq_pos, Tensor(g!) step_counter, int max_pos, Tensor(h!) workspace) -> ()")
 
 _fe = None
 
@@ -75,7 +89,116 @@ def _gemm_fp8_meta(aq, a_scale, wq, w_scale, bias, act, residual):
     return aq.new_empty((aq.shape[0], n), dtype=torch.bfloat16)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# stateful entry points
+import ctypes as C  # noqa: E402
+
+
+def weights_blob(struct) -> torch.Tensor:
+    """The opaque `weights` argument: a uint8 CPU tensor that ALIASES a packed-weight ctypes struct (no copy; the struct -- and the
+    tensors / pointer arrays it points to -- must stay alive as long as the blob is used: the modules keep both in `pack()`)."""
+    return torch.frombuffer(struct, dtype=torch.uint8)
+
+
+def _struct(blob: torch.Tensor, typ):
+    if blob.device.type != "cpu" or blob.dtype != torch.uint8 or blob.numel() != C.sizeof(typ):
+        raise L.AfhipError(f"weights must be the uint8 CPU blob of a {typ.__name__} ({C.sizeof(typ)} bytes)")
+    return C.cast(blob.data_ptr(), C.POINTER(typ))
+
+
+def _kv(k_cache, v_cache):
+    s = L.KvCache()
+    s.k, s.v, s.cap, s.B = k_cache.data_ptr(), v_cache.data_ptr(), k_cache.shape[3], k_cache.shape[1]
+    return s
+
+
+def _enc_dims(blob):
+    w = _struct(blob, L.EncoderWeights).contents
+    return w.max_pos, w.d_model
+
+
+def _encoder_forward(weights, mel_btc, feat_len, hidden_layer, workspace):
+    lib = L.lib()
+    w = _struct(weights, L.EncoderWeights)
+    B = mel_btc.shape[0]
+    Tp, d = w.contents.max_pos, w.contents.d_model
+    out = torch.empty((B, Tp // 2, d), dtype=mel_btc.dtype, device=mel_btc.device)
+    hid = torch.empty((B, Tp, d) if hidden_layer >= -1 else (0,), dtype=mel_btc.dtype, device=mel_btc.device)
+    L.check(lib.afhip_encoder_forward(w, L.ptr(mel_btc), L.ptr(feat_len), B, L.ptr(out), L.ptr(hid) if hidden_layer >= -1 else None,
+                                      hidden_layer if hidden_layer >= -1 else -1, L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+    return out, hid
+
+
+def _encoder_forward_meta(weights, mel_btc, feat_len, hidden_layer, workspace):
+    Tp, d = _enc_dims(weights)
+    B = mel_btc.shape[0]
+    return mel_btc.new_empty((B, Tp // 2, d)), mel_btc.new_empty((B, Tp, d) if hidden_layer >= -1 else (0,))
+
+
+def _encoder_forward_ragged(weights, mel_btc, feat_len, feat_len_host, workspace):
+    lib = L.lib()
+    w = _struct(weights, L.EncoderWeights)
+    B = mel_btc.shape[0]
+    out = torch.empty((B, w.contents.max_pos // 2, w.contents.d_model), dtype=mel_btc.dtype, device=mel_btc.device)
+    L.check(lib.afhip_encoder_forward_ragged(w, L.ptr(mel_btc), L.ptr(feat_len), feat_len_host.data_ptr(), B, L.ptr(out),
+                                             L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+    return out
+
+
+def _encoder_forward_ragged_meta(weights, mel_btc, feat_len, feat_len_host, workspace):
+    Tp, d = _enc_dims(weights)
+    return mel_btc.new_empty((mel_btc.shape[0], Tp // 2, d))
+
+
+def _llm_forward(weights, x, pos0, k_cache, v_cache, workspace):
+    lib = L.lib()
+    B, T = x.shape[0], x.shape[1]
+    hid = torch.empty_like(x)
+    cs = _kv(k_cache, v_cache)
+    L.check(lib.afhip_llm_forward(_struct(weights, L.LlmWeights), L.ptr(x), B, T, pos0, C.byref(cs), L.ptr(hid), L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+    return hid
+
+
+def _llm_forward_ragged(weights, x, seq_pos, max_pos, k_cache, v_cache, workspace):
+    lib = L.lib()
+    hid = torch.empty_like(x)
+    cs = _kv(k_cache, v_cache)
+    L.check(lib.afhip_llm_forward_ragged(_struct(weights, L.LlmWeights), L.ptr(x), x.shape[0], L.ptr(seq_pos), max_pos, C.byref(cs), L.ptr(hid),
+                                         L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+    return hid
+
+
+def _lm_head(weights, hidden_rows, n_stream, workspace):
+    lib = L.lib()
+    w = _struct(weights, L.LlmWeights)
+    n = hidden_rows.shape[0]
+    logits = torch.empty((n, n_stream, w.contents.vocab), dtype=torch.float32, device=hidden_rows.device)
+    L.check(lib.afhip_lm_head(w, L.ptr(hidden_rows), n, n_stream, L.ptr(logits), L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+    return logits
+
+
+def _lm_head_meta(weights, hidden_rows, n_stream, workspace):
+    return hidden_rows.new_empty((hidden_rows.shape[0], n_stream, _struct(weights, L.LlmWeights).contents.vocab), dtype=torch.float32)
+
+
+def _llm_decode_step(weights, k_cache, v_cache, prev_token, out_tokens, finished_at, allowed, eos_id, eot_id, seq_pos, step_counter, max_pos, workspace):
+    lib = L.lib()
+    st = L.DecodeState()
+    st.prev_token, st.out_tokens, st.finished_at = prev_token.data_ptr(), out_tokens.data_ptr(), finished_at.data_ptr()
+    st.allowed, st.n_iv, st.eos_id, st.eot_id = allowed.data_ptr(), allowed.shape[0], eos_id, eot_id
+    st.seq_pos, st.step_counter = seq_pos.data_ptr(), step_counter.data_ptr()
+    cs = _kv(k_cache, v_cache)
+    L.check(lib.afhip_llm_decode_step(_struct(weights, L.LlmWeights), C.byref(cs), C.byref(st), prev_token.shape[0], max_pos, 0,
+                                      L.ptr(workspace), workspace.numel(), L.stream_ptr()))
+
+
 _impls = {
+    "encoder_forward": (_encoder_forward, _encoder_forward_meta),
+    "encoder_forward_ragged": (_encoder_forward_ragged, _encoder_forward_ragged_meta),
+    "llm_forward": (_llm_forward, lambda weights, x, pos0, k_cache, v_cache, workspace: torch.empty_like(x)),
+    "llm_forward_ragged": (_llm_forward_ragged, lambda weights, x, seq_pos, max_pos, k_cache, v_cache, workspace: torch.empty_like(x)),
+    "lm_head": (_lm_head, _lm_head_meta),
+    "llm_decode_step": (_llm_decode_step, lambda *a: None),
     "gemm": (_gemm, _gemm_meta),
     "layernorm": (lambda x, w, b, eps: ops.layernorm(x, w, b, eps), lambda x, w, b, eps: torch.empty_like(x)),
     "rmsnorm": (lambda x, w, eps: ops.rmsnorm(x, w, eps), lambda x, w, eps: torch.empty_like(x)),

@@ -240,7 +240,8 @@ def test_torch_library_ops_registered_with_meta_kernels():
     import torch
     import audio_intelligence_amd.torch_ops as T
     from torch._subclasses.fake_tensor import FakeTensorMode
-    assert T.OP_NAMES == sorted(["gemm", "layernorm", "rmsnorm", "embed_sum", "attention_packed", "log_mel", "quant_rows", "gemm_fp8"])
+    assert T.OP_NAMES == sorted(["gemm", "layernorm", "rmsnorm", "embed_sum", "attention_packed", "log_mel", "quant_rows", "gemm_fp8",
+                                 "encoder_forward", "encoder_forward_ragged", "llm_forward", "llm_forward_ragged", "lm_head", "llm_decode_step"])
     for n in T.OP_NAMES:
         assert hasattr(torch.ops.afhip, n)
     with FakeTensorMode():
@@ -256,6 +257,28 @@ def test_torch_library_ops_registered_with_meta_kernels():
         assert tuple(mel.shape) == (4, 3000, 128) and mel.dtype == torch.bfloat16
         att = torch.ops.afhip.attention_packed(torch.empty((2, 1500, 3840), dtype=torch.bfloat16, device="cuda"), 20, None, False)
         assert tuple(att.shape) == (2, 1500, 1280)
+    # the stateful entry points (the ones that carry the time) take the packed-weight struct as an opaque uint8 CPU tensor that aliases it
+    from audio_intelligence_amd import _lib as L
+    ew = L.EncoderWeights()
+    ew.max_pos, ew.d_model = 1500, 1280
+    blob = T.weights_blob(ew)
+    assert blob.dtype == torch.uint8 and blob.numel() == __import__("ctypes").sizeof(L.EncoderWeights)
+    ew.d_model = 384                                                   # aliasing, not a copy
+    out, hid = torch.ops.afhip.encoder_forward(blob, torch.empty((2, 3000, 128), device="meta"), None, -2, torch.empty(8, dtype=torch.uint8, device="meta"))
+    assert tuple(out.shape) == (2, 750, 384) and hid.numel() == 0
+    out, hid = torch.ops.afhip.encoder_forward(blob, torch.empty((2, 3000, 128), device="meta"), None, 0, torch.empty(8, dtype=torch.uint8, device="meta"))
+    assert tuple(hid.shape) == (2, 1500, 384)
+    lw = L.LlmWeights()
+    lw.vocab = 24840
+    lb = T.weights_blob(lw)
+    lg = torch.ops.afhip.lm_head(lb, torch.empty((4, 768), device="meta"), 8, torch.empty(8, dtype=torch.uint8, device="meta"))
+    assert tuple(lg.shape) == (4, 8, 24840) and lg.dtype == torch.float32
+    x = torch.empty((2, 5, 768), dtype=torch.bfloat16, device="meta")
+    kv = torch.empty((12, 2, 2, 64, 64), dtype=torch.bfloat16, device="meta")
+    assert tuple(torch.ops.afhip.llm_forward(lb, x, 0, kv, kv.clone(), torch.empty(8, dtype=torch.uint8, device="meta")).shape) == (2, 5, 768)
+    import pytest as _pt
+    with _pt.raises(L.AfhipError):
+        torch.ops.afhip.lm_head(blob, torch.empty((4, 768), device="meta"), 8, torch.empty(8, dtype=torch.uint8, device="meta"))   # wrong struct
     # real CPU tensors: no kernel for that backend -> an error, never a silent fallback
     import pytest
     with pytest.raises((NotImplementedError, RuntimeError)):
