@@ -50,6 +50,11 @@ constexpr int PP_HALF = 16384;           // 128 rows x 128 B
 constexpr int PP_STAGE = 4 * PP_HALF;    // A0 A1 B0 B1
 constexpr int PP_OFF_A0 = 0, PP_OFF_A1 = PP_HALF, PP_OFF_B0 = 2 * PP_HALF, PP_OFF_B1 = 3 * PP_HALF;
 constexpr int PP_LDS = 2 * PP_STAGE;     // 128 KiB
+#ifdef AFHIP_PP_STAMPS   /* diagnostic build: -DAFHIP_PP_STAMPS, tools/gemm_stamps.py (never the product library) */
+constexpr int PP_LDS_TOTAL = PP_LDS + 1024;   // + 64 s_memtime stamps for each of waves 0 and 4 of workgroup 0
+#else
+constexpr int PP_LDS_TOTAL = PP_LDS;
+#endif
 
 struct PPArgs {
     const char* A;
@@ -69,6 +74,9 @@ struct PPArgs {
     const float* a_scale;     // F8: [M] f32 scale of each e4m3 activation row
     const float* w_scale;     // F8: [N] f32 scale of each e4m3 weight row (output channel)
     int esz;                  // operand element size in bytes: 2 (bf16) or 1 (e4m3)
+#ifdef AFHIP_PP_STAMPS
+    unsigned long long* dbg;  // AFHIP_PP_DBGPTR: [2][64] stamps (waves 0 and 4 of workgroup 0, second output tile)
+#endif
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -144,12 +152,28 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
 #define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #endif
 #define PP_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#ifndef PP_SCHED
+#define PP_SCHED 2   /* schedule of the 8 half-tile slots; round-3 same-box A/B at M = 48000 in profiles/r03_gemm_pp_sched_ab.txt.
+                        0: one half-tile DMA per phase (B1, A1 of tile t+1, A0, B0 of tile t+2); fragment reads per LOAD section 12 / 4 / 8 / 0.
+                        1: DMAs A1(t+1) | - | A0 B0 (t+2) | B1(t+2): every slot refilled exactly 2 phases after its read, 5 phases (80 KiB) of
+                           DMA lookahead instead of 4.  0-7 % SLOWER (fc2 0.502 -> 0.540 ms): the kernel is not short of lookahead, and the
+                           two-DMA LOAD section of phase 2 outlasts the partner's MFMA section.
+                        2: schedule 0 with K half 0 of the next tile's A0 fragments read in phase 3 (A0 is the one half-tile with a spare
+                           phase of DMA slack, so its landing wait moves to phase 2): reads 8 / 4 / 8 / 4.  +1.5-3 % on qkv / out / fc1+gelu,
+                           fc1 plain and fc2 unchanged; bf16 only (the e4m3 form reads both K halves as one operand and keeps 0) */
+#endif
+#define PP_WAIT_VM10() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
 #define PP_BARRIER()                              \
     do {                                          \
         __builtin_amdgcn_sched_barrier(0);        \
         __builtin_amdgcn_s_barrier();             \
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
+#ifdef AFHIP_PP_STAMPS
+#define PP_STAMP() do { if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && st_idx < 64) st_base[st_idx] = t_; ++st_idx; } } while (0)
+#else
+#define PP_STAMP() do { } while (0)
+#endif
 
 // F8: both operands are OCP e4m3 bytes (K tile = 128 elements = the same 128-byte LDS rows, so staging, swizzle, phases and
 // vmcnt counts are untouched); a quadrant is 8 x v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 127) -- twice the
@@ -168,6 +192,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int n_my = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nk2 = (p.K * (F8 ? 1 : 2)) / (4 * PP_BK);          // pairs of 128-byte K tiles
+#ifdef AFHIP_PP_STAMPS
+    const bool st_wave = p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4);
+    bool st_on = false;
+    int st_idx = 0;
+    volatile unsigned long long* st_base = reinterpret_cast<volatile unsigned long long*>(smem + PP_LDS) + (wave ? 64 : 0);
+#endif
 
     // ---- DMA lane constants: instruction u of this wave fills LDS rows (u*8 + wave)*8 + lrow of a half-tile ----
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -204,6 +234,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    bf16x8 fa0k0[4];                        // PP_SCHED 2: K half 0 of the NEXT tile's A0 fragments, read one phase early
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef int v8i_t __attribute__((ext_vector_type(8)));
     const int unit_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte: block scales off
@@ -219,10 +250,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     pp_cur_advance(p, c1, n_my);                  // stream tile 1
     pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[0][0], voffA[0][1], dma_dst + PP_STAGE + PP_OFF_A0);
     pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[0][0], voffB[0][1], dma_dst + PP_STAGE + PP_OFF_B0);
+#if PP_SCHED == 1
+    pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_STAGE + PP_OFF_B1);
+#endif
     c2 = c1;
     pp_cur_advance(p, c2, n_my);                  // stream tile 2
+#if PP_SCHED == 1
+    PP_WAIT_VM10();                               // A0(0), B0(0) of this wave have landed (5 half-tiles younger)
+#else
     PP_WAIT_VM8();                                // A0(0), B0(0) of this wave have landed
+#endif
     PP_BARRIER();
+#if PP_SCHED == 2
+    if constexpr (!F8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + PP_OFF_A0 + aoff0 + i * 2048);
+    }
+#endif
     if (grp == 1) PP_BARRIER();                   // stagger: group 1 runs one barrier behind group 0
 
     // 16 MFMAs of one quadrant; with PP_DMA_IN_MFMA the phase's LDS-DMA half-tile is issued between the two K halves, in the
@@ -256,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
+                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], (PP_SCHED == 2 && !F8 && HA == 0 && kk == 0) ? fa0k0[i] : fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
 #if PP_DMA_IN_MFMA
             if (kk == 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -329,20 +373,64 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         auto dma1 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
         auto dma2 = [&]() { pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0); };
         auto dma3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0); };
+#if PP_SCHED == 1
+        // issue order of a K tile: A1(t+1) | - | A0(t+2) B0(t+2) | B1(t+2); in the stream that is the natural order A0 B0 B1 A1 of
+        // every tile, so each counted wait below leaves exactly the younger half-tiles (2 instructions each) in flight
+        auto x0 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
+        auto x3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[1][0], voffB[1][1], d_same + PP_OFF_B1); };
+        auto nodma = [&]() {};
+        // phase 0: reads A0 B0 (t); refills A1 of the other stage (read in phase 2 of tile t-1)
+        read_b(st + PP_OFF_B0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(st + PP_OFF_A0);
+        x0();
+        PP_WAIT_VM10();                           // B1(t) landed; A1(t) A0 B0 B1 (t+1) A1(t+1) in flight
+        PP_BARRIER();
+        mfma_quad(I0{}, I0{}, fb0, nodma);
+        PP_BARRIER();
+        // phase 1: reads B1 (t)
+        read_b(st + PP_OFF_B1, fb1);
+        PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 A1 (t+1) in flight
+        PP_BARRIER();
+        mfma_quad(I0{}, I1{}, fb1, nodma);
+        PP_BARRIER();
+        // phase 2: reads A1 (t); refills A0 and B0 of this stage (read in phase 0)
+        read_a(st + PP_OFF_A1);
+        dma2();
+        dma3();
+        PP_BARRIER();
+        mfma_quad(I1{}, I1{}, fb1, nodma);
+        PP_BARRIER();
+        // phase 3: refills B1 of this stage (read in phase 1)
+        x3();
+        PP_WAIT_VM10();                           // A0 B0 (t+1) landed; B1 A1 (t+1) A0 B0 B1 (t+2) in flight
+        PP_BARRIER();
+        mfma_quad(I1{}, I0{}, fb0, nodma);
+        PP_BARRIER();
+#else
         // phase 0
 #if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
         dma0();
 #endif
         read_b(st + PP_OFF_B0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(st + PP_OFF_A0);
+        if constexpr (PP_SCHED == 2 && !F8) {     // K half 0 of these fragments was read in phase 3 of the previous K tile
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(st + PP_OFF_A0 + aoff1 + i * 2048);
+        } else {
+            read_a(st + PP_OFF_A0);
+        }
 #if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma0();
 #endif
         PP_WAIT_VM();
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         mfma_quad(I0{}, I0{}, fb0, dma0);
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         // phase 1
 #if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
         dma1();
@@ -352,9 +440,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         dma1();
 #endif
         PP_WAIT_VM();
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         mfma_quad(I0{}, I1{}, fb1, dma1);
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         // phase 2
 #if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
         dma2();
@@ -363,26 +455,51 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma2();
 #endif
+        if constexpr (PP_SCHED == 2 && !F8) PP_WAIT_VM8();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         mfma_quad(I1{}, I1{}, fb1, dma2);
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         // phase 3
+        if constexpr (PP_SCHED == 2 && !F8) {     // balance the LOAD sections (12 / 4 / 8 / 0 fragment reads -> 8 / 4 / 8 / 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + (S ^ 1) * PP_STAGE + PP_OFF_A0 + aoff0 + i * 2048);
+        }
 #if !PP_DMA_IN_MFMA
         dma3();
 #endif
         PP_WAIT_VM();
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
         mfma_quad(I1{}, I0{}, fb0, dma3);
+        PP_STAMP();
         PP_BARRIER();
+        PP_STAMP();
+#endif
         c1 = c2;
         pp_cur_advance(p, c2, n_my);
     };
 
     for (int it = 0; it < n_my; ++it) {
         for (int k2 = 0; k2 < nk2; ++k2) {
+#ifdef AFHIP_PP_STAMPS
+            st_on = st_wave && it == 1 && k2 == 4;
+#endif
             ktile(I0{});
+#ifdef AFHIP_PP_STAMPS
+            st_on = false;
+#endif
             ktile(I1{});
         }
+#ifdef AFHIP_PP_STAMPS
+        st_on = st_wave && it == 1;
+        if (st_on) st_idx = 40;
+        PP_STAMP();                               // 40: epilogue starts
+#endif
         // ---- epilogue straight from registers (no LDS, no barrier): lane (c, q) owns, for each of its 8 rows, the 8
         //      consecutive columns q*8 .. q*8+7 of both 32-column halves of the wave's 64 columns ----
         int m0, n0;
@@ -474,6 +591,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     st2[ha][i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)m);
                 }
         }
+        PP_STAMP();                               // 41: epilogue operand loads issued
         float rs[2][4], rss[2][4];
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
@@ -532,9 +650,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                     }
             }
         }
+        PP_STAMP();                               // 42: epilogue math done, stores issued
+#ifdef AFHIP_PP_STAMPS
+        st_on = false;
+#endif
     }
     if (grp == 0) PP_BARRIER();                   // pairs with group 1's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#ifdef AFHIP_PP_STAMPS
+    if (st_wave) p.dbg[(wave ? 64 : 0) + lane] = st_base[lane];
+#endif
 }
 
 bool pp_enabled() {
@@ -557,9 +682,9 @@ template <int ACT, bool HB, bool HR, bool LF = false, bool ST = false, bool F8 =
 void pp_launch_t(const PPArgs& p, int grid, hipStream_t s) {
     static unsigned long long attr_done = 0;
     if (afhip_first_use_on_device(&attr_done)) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>), dim3((unsigned)grid), dim3(512), PP_LDS, s, p);
+    hipLaunchKernelGGL((gemm_pp_kernel<ACT, HB, HR, LF, ST, F8>), dim3((unsigned)grid), dim3(512), PP_LDS_TOTAL, s, p);
 }
 
 }  // namespace
@@ -608,6 +733,9 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     p.ldc = a->ldc; p.ldres = a->ldres;
     p.act = a->act;
     p.tiles_m = cdiv(a->M, PP_BM); p.tiles_n = a->N / PP_BN; p.group_m = group_m;
+#ifdef AFHIP_PP_STAMPS
+    { const char* e = getenv("AFHIP_PP_DBGPTR"); p.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr; }
+#endif
     const long long nwg = (long long)p.tiles_m * p.tiles_n;
     AFHIP_CHECK(nwg < (1ll << 30), "afhip_gemm: grid too large");
     const int ncu = pp_num_cus();
