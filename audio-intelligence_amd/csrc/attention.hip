@@ -594,6 +594,7 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 }  // namespace
 
 bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s);   // attention_enc.hip: the one-wave-per-SIMD encoder form
+bool afhip_attention_enc64x8(const afhip_attn_args* a, hipStream_t s); // attention_enc8.hip: the two-waves-per-SIMD encoder form (AFHIP_ATTN_ENC8=0: off)
 
 extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_attention: null args");
@@ -613,6 +614,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
 
     if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
+    if (afhip_attention_enc64x8(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
     if (afhip_attention_enc64(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
 
     AttnP p;

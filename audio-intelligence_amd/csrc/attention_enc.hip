@@ -38,6 +38,19 @@ constexpr int E_RING = E_NST * E_STAGEB;         // 64 KiB
 constexpr int E_OROW = 144;                      // O staging row: 128 B + 16 B pad
 constexpr int E_QOFF = E_RING + 4 * 64 * E_OROW; // + 36 KiB of O staging (one private 64-row area per wave)
 constexpr int E_LDS = E_QOFF + E_QT * E_ROWB;    // + 32 KiB: the block's Q rows (each wave DMAs and reads its own 64)
+#ifdef AFHIP_ENC_STAMPS   /* diagnostic build: -DAFHIP_ENC_STAMPS, tools/attn_enc_stamps.py (never the product library) */
+constexpr int E_LDS_TOTAL = E_LDS;
+// A stamp is one s_memtime and one SCALAR store straight to the debug buffer (gfx9 still has s_store): no VGPR, no LDS, no vmcnt traffic,
+// no state of its own -- the slot comes from (wave, t, K), the condition from values the loop keeps live anyway.  The kernel has no VGPR
+// to spare: two more live values and hipcc parks one in the (asm-owned) accumulator file, which is a memory fault (Makefile guard).
+#define E_STAMP(K) do { if (p.dbg && blockIdx.x == 0 && v == (int)(blockIdx.x + 2 * gridDim.x) && t >= 8 && t < 16 && (wave == 0 || wave == 3)) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                                               \
+        const int off_ = ((wave ? 64 : 0) + (t - 8) * 5 + (K)) * 8;                                                                                \
+        asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(t_), "s"(p.dbg), "s"(off_) : "memory"); } } while (0)
+#else
+constexpr int E_LDS_TOTAL = E_LDS;
+#define E_STAMP(K) do { } while (0)
+#endif
 constexpr float E_LAG_LIMIT = 65536.f;
 
 struct EncAttnP {
@@ -49,6 +62,9 @@ struct EncAttnP {
     long long q_bs, kv_bs, o_bs;
     long long q_hs, kv_hs, o_hs;
     int n_qt, n_blk;
+#ifdef AFHIP_ENC_STAMPS
+    unsigned long long* dbg;    // AFHIP_ENC_DBGPTR: [2][64] stamps
+#endif
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -128,6 +144,15 @@ constexpr int A_OA = 0, A_OB = 32, A_QA = 64, A_QB = 80, A_KF = 96, A_VF = 160;
 #define E_READ_V(SET, I, STAGE) asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%5\n\tds_read_b64_tr_b16 a[%3:%4], %0 offset:%6" :: "v"(vaddr[(I) & 1]), \
                                              "n"(A_VF + (SET) * 32 + (I) * 4), "n"(A_VF + (SET) * 32 + (I) * 4 + 1), "n"(A_VF + (SET) * 32 + (I) * 4 + 2), "n"(A_VF + (SET) * 32 + (I) * 4 + 3), \
                                              "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048), "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048 + 512) : "memory")
+
+// one half (H = 0, 1) of V fragment i
+#define E_READ_VH(SET, I, H, STAGE) asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%3" :: "v"(vaddr[(I) & 1]), \
+                                             "n"(A_VF + (SET) * 32 + (I) * 4 + 2 * (H)), "n"(A_VF + (SET) * 32 + (I) * 4 + 2 * (H) + 1), \
+                                             "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048 + 512 * (H)) : "memory")
+#ifndef E_LDS_SPREAD
+#define E_LDS_SPREAD 0   /* where a tile's 24 fragment reads sit.  0: MFMA gaps 0-7 of slot 1 carry three each (K, V lo, V hi).  1: slot 1 carries K in gaps
+                            0-7 and one V half in every gap.  2: one read per gap: K in slot 1 gaps 0-7, V halves in slot 1 gaps 8-15 and slot 2 gaps 0-7 */
+#endif
 
 // everything a block (query tile, head, clip) needs, wave-uniform
 struct EncBlk {
@@ -415,9 +440,12 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 constexpr int IDX = decltype(idx_tag)::value;
                 constexpr int PAR = IDX & 1, NXT = PAR ^ 1;
                 // tile t+1 must have landed before its K fragments are read in slot 1; tile t+2 (4 DMA instructions) may stay in flight
+                E_STAMP(0);                                    // 0: tile starts
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                E_STAMP(1);                                    // 1: tile t+1 landed (this wave's part)
                 E_BARRIER();
+                E_STAMP(2);                                    // 2: barrier passed
                 if (t + 3 < nt) dma_tile(cur, t + 3);          // stage (t+3)&3 = (t-1)&3: last read (V(t-1)) before the barrier above
                 E_FENCE();
                 // ---- slot 1 ----
@@ -427,13 +455,22 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                     (void)&sb; (void)&cb; (void)&pkb; (void)&kaddr; (void)&vaddr;
                     E_SLOT_MFMA(i, sb, PAR, A_QB, cb, A_OB, PAR, pkb);
                     soft2(i, sa, pka, ps4);
+#if E_LDS_SPREAD == 0
                     if constexpr (i < 8) { E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1)); E_READ_V(NXT, i, IDX); }
+#elif E_LDS_SPREAD == 1
+                    if constexpr (i < 8) E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1));
+                    E_READ_VH(NXT, i >> 1, i & 1, IDX);
+#else
+                    if constexpr (i < 8) E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1));
+                    else E_READ_VH(NXT, (i - 8) >> 1, (i - 8) & 1, IDX);
+#endif
                     E_FENCE();
                 });
                 float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
                 if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OA>{}, sa, pka, ca, ml_a, l_a, dsh, ps);
                 if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sa, dsh); }
                 l_a += ps;
+                E_STAMP(3);                                    // 3: slot 1 issued
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments read in slot 1 are in their registers
                 E_FENCE();
                 // ---- slot 2 ----
@@ -441,14 +478,21 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 static_for<0, 16>([&](auto it) {
                     constexpr int i = decltype(it)::value;
                     (void)&sa; (void)&ca; (void)&pka;
+#if E_LDS_SPREAD == 2
+                    if constexpr (i == 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); E_FENCE(); }   // V(t) halves 8..15 are in their registers
+#endif
                     E_SLOT_MFMA(i, sa, NXT, A_QA, ca, A_OA, NXT, pka);
                     soft2(i, sb, pkb, ps4);
+#if E_LDS_SPREAD == 2
+                    if constexpr (i < 8) { (void)&vaddr; E_READ_VH(NXT, (i + 8) >> 1, (i + 8) & 1, IDX); }
+#endif
                     E_FENCE();
                 });
                 ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
                 if (E_REBASE_COND(ps)) ps = rebase(std::integral_constant<int, A_OB>{}, sb, pkb, cb, ml_b, l_b, dsh, ps);
                 if (has_edge && t == nt - 1) { asm volatile("" ::: "memory"); ps -= dup_sum(sb, dsh); }
                 l_b += ps;
+                E_STAMP(4);                                    // 4: slot 2 issued
                 E_FENCE();
             };
             for (int t = 0; t < nt; t += 4) {
@@ -511,6 +555,9 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
         cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AFHIP_ENC_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 }  // namespace
@@ -534,14 +581,17 @@ bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s) {
     const long long nblk = (long long)p.n_qt * a->n_q * a->B;
     if (nblk >= (1ll << 31)) return false;
     p.n_blk = (int)nblk;
+#ifdef AFHIP_ENC_STAMPS
+    { const char* e = getenv("AFHIP_ENC_DBGPTR"); p.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr; }
+#endif
     static unsigned long long attr_done = 0;
     if (afhip_first_use_on_device(&attr_done))
-        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_enc64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_TOTAL);
     // persistent: one workgroup per CU (the whole register file per wave), a multiple of 8 so that a workgroup keeps its XCD residue
     int ncu = afhip_cu_count();
     ncu = ncu >= 8 ? (ncu / 8) * 8 : ncu;
     int grid = nblk < ncu ? (int)nblk : ncu;
     { const char* e = getenv("AFHIP_ENC64_ONE_BLOCK_PER_WG"); if (e && e[0] == '1') grid = (int)nblk; }   // A/B switch, read per call
-    hipLaunchKernelGGL(attn_enc64_kernel, dim3((unsigned)grid), dim3(256), E_LDS, s, p);
+    hipLaunchKernelGGL(attn_enc64_kernel, dim3((unsigned)grid), dim3(256), E_LDS_TOTAL, s, p);
     return true;
 }

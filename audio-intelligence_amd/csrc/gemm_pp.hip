@@ -51,7 +51,7 @@ constexpr int PP_STAGE = 4 * PP_HALF;    // A0 A1 B0 B1
 constexpr int PP_OFF_A0 = 0, PP_OFF_A1 = PP_HALF, PP_OFF_B0 = 2 * PP_HALF, PP_OFF_B1 = 3 * PP_HALF;
 constexpr int PP_LDS = 2 * PP_STAGE;     // 128 KiB
 #ifdef AFHIP_PP_STAMPS   /* diagnostic build: -DAFHIP_PP_STAMPS, tools/gemm_stamps.py (never the product library) */
-constexpr int PP_LDS_TOTAL = PP_LDS + 1024;   // + 64 s_memtime stamps for each of waves 0 and 4 of workgroup 0
+constexpr int PP_LDS_TOTAL = PP_LDS;
 #else
 constexpr int PP_LDS_TOTAL = PP_LDS;
 #endif
@@ -170,7 +170,10 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 #ifdef AFHIP_PP_STAMPS
-#define PP_STAMP() do { if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && st_idx < 64) st_base[st_idx] = t_; ++st_idx; } } while (0)
+// one s_memtime and one SCALAR store straight to the debug buffer (gfx9 still has s_store): no VGPR, no LDS, and -- unlike a vector or
+// FLAT store -- nothing on vmcnt, which the DMA stream's counted waits own
+#define PP_STAMP() do { if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); const int off_ = ((wave ? 64 : 0) + st_idx) * 8; \
+        if (st_idx < 64) asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(t_), "s"(p.dbg), "s"(off_) : "memory"); ++st_idx; } } while (0)
 #else
 #define PP_STAMP() do { } while (0)
 #endif
@@ -196,7 +199,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     const bool st_wave = p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4);
     bool st_on = false;
     int st_idx = 0;
-    volatile unsigned long long* st_base = reinterpret_cast<volatile unsigned long long*>(smem + PP_LDS) + (wave ? 64 : 0);
 #endif
 
     // ---- DMA lane constants: instruction u of this wave fills LDS rows (u*8 + wave)*8 + lrow of a half-tile ----
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     if (grp == 0) PP_BARRIER();                   // pairs with group 1's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 #ifdef AFHIP_PP_STAMPS
-    if (st_wave) p.dbg[(wave ? 64 : 0) + lane] = st_base[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
 

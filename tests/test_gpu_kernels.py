@@ -811,3 +811,39 @@ def test_attention_prescaled_small_and_ragged_shapes(T):
         r = _ref_attention_exp2(qs.float()[b:b + 1, :n], kb.float()[b:b + 1, :n], vb.float()[b:b + 1, :n])[0]
         assert float((o2[off: off + n] - r).abs().max()) <= 2e-2 + 2e-2 * float(r.abs().max()), (T, b)
         off += n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,lens", [(1500, None), (1500, [1500, 777, 64]), (700, [700, 1, 65]), (257, [257, 130, 2])])
+def test_attention_encoder_two_forms_bit_identical(T, lens, monkeypatch):
+    """attention_enc8.hip (8 waves x 32 queries, two waves per SIMD half a tile apart; opt-in, AFHIP_ATTN_ENC8=1) and attention_enc.hip
+    (4 waves x 64 queries, the default) run the same MFMA sequence per accumulator, the same four partial row sums and the same lag rule:
+    their outputs must be equal BIT FOR BIT -- full clips, ragged key lengths with a spike that raises the lag, and packed rows."""
+    from audio_intelligence_amd import ops
+    B, H = 3, 20
+    g = torch.Generator().manual_seed(T + (len(lens) if lens else 0))
+    qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * 0.7)
+    qkv[:, :, : H * 64] *= 0.125 * math.log2(math.e) * 3.0
+    qkv[1, T // 2, H * 64: 2 * H * 64] *= 12.0          # one key far above the first tile's maximum: the lag has to move
+    qkv = qkv.to(torch.bfloat16).to(_dev())
+    kl = torch.tensor(lens, dtype=torch.int32, device=_dev()) if lens else None
+
+    def both(fn):
+        monkeypatch.setenv("AFHIP_ATTN_ENC8", "1")
+        a = fn()
+        monkeypatch.setenv("AFHIP_ATTN_ENC8", "0")
+        b = fn()
+        torch.cuda.synchronize()
+        return a, b
+
+    a, b = both(lambda: ops.attention_packed(qkv, H, key_len=kl, q_prescaled=True))
+    if lens:
+        for i, n in enumerate(lens):
+            a[i, n:] = 0
+            b[i, n:] = 0
+    assert bool(torch.isfinite(a.float()).all())
+    assert torch.equal(a, b)
+    if lens:
+        rows = torch.cat([qkv[i, :n] for i, n in enumerate(lens)], 0).contiguous()
+        a, b = both(lambda: ops.attention_ragged(rows, H, torch.tensor(lens, dtype=torch.int32), max(lens), q_prescaled=True))
+        assert torch.equal(a, b)
