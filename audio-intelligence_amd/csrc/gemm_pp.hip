@@ -237,6 +237,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
     bf16x8 fa0k0[4];                        // PP_SCHED 2: K half 0 of the NEXT tile's A0 fragments, read one phase early
+    // ... except in the two forms whose epilogue (bias + residual + row statistics, or + GELU) already needs all 256 registers: the 16
+    // fragment registers that then stay live across it spill 7-24 VGPRs, and fc2 (the statistics form) gained nothing from the schedule
+    constexpr bool EARLY_A0 = PP_SCHED == 2 && !F8 && !(HAS_BIAS && HAS_RES && (STATS || ACT == AFHIP_ACT_GELU));
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef int v8i_t __attribute__((ext_vector_type(8)));
     const int unit_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte: block scales off
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #endif
     PP_BARRIER();
 #if PP_SCHED == 2
-    if constexpr (!F8) {
+    if constexpr (EARLY_A0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + PP_OFF_A0 + aoff0 + i * 2048);
     }
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], (PP_SCHED == 2 && !F8 && HA == 0 && kk == 0) ? fa0k0[i] : fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
+                    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], (EARLY_A0 && HA == 0 && kk == 0) ? fa0k0[i] : fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
 #if PP_DMA_IN_MFMA
             if (kk == 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #endif
         read_b(st + PP_OFF_B0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PP_SCHED == 2 && !F8) {     // K half 0 of these fragments was read in phase 3 of the previous K tile
+        if constexpr (EARLY_A0) {     // K half 0 of these fragments was read in phase 3 of the previous K tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(st + PP_OFF_A0 + aoff1 + i * 2048);
         } else {
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma2();
 #endif
-        if constexpr (PP_SCHED == 2 && !F8) PP_WAIT_VM8();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
+        if constexpr (EARLY_A0) PP_WAIT_VM8();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_BARRIER();
         PP_STAMP();
         // phase 3
-        if constexpr (PP_SCHED == 2 && !F8) {     // balance the LOAD sections (12 / 4 / 8 / 0 fragment reads -> 8 / 4 / 8 / 4)
+        if constexpr (EARLY_A0) {     // balance the LOAD sections (12 / 4 / 8 / 0 fragment reads -> 8 / 4 / 8 / 4)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + (S ^ 1) * PP_STAGE + PP_OFF_A0 + aoff0 + i * 2048);
         }

@@ -503,13 +503,22 @@ void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
 }
 
 template <typename T, int NT>
-void launch_mt(const SkinnyP& p, int mt, int amode, hipStream_t s) {
+bool launch_mt(const SkinnyP& p, int mt, int amode, hipStream_t s) {
     switch (mt) {
         case 1: launch_mode<T, NT, 1>(p, amode, s); break;
         case 2: launch_mode<T, NT, 2>(p, amode, s); break;
-        case 3: launch_mode<T, NT, 3>(p, amode, s); break;
-        default: launch_mode<T, NT, 4>(p, amode, s); break;
+        default:
+            // NT = 4 is only ever chosen with mt <= 2 (the `wide` rule: 8 KiB of combine LDS per tile); not instantiating <*, 4, 3..4, *> keeps
+            // their 60-154 spilled registers out of the binary altogether (every skinny kernel that CAN run is spill-free: tools/check_spills.py)
+            if constexpr (NT < 4) {
+                if (mt == 3) launch_mode<T, NT, 3>(p, amode, s);
+                else launch_mode<T, NT, 4>(p, amode, s);
+            } else {
+                return false;
+            }
+            break;
     }
+    return true;
 }
 
 }  // namespace
@@ -590,17 +599,19 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
             return 0;
         }
     }
+    bool ok;
     if (a->dtype == AFHIP_BF16) {
-        if (sw_out) launch_mt<bf16, 2>(p, mt, amode, s);
-        else if (wide) launch_mt<bf16, 4>(p, mt, amode, s);
-        else if (nt_narrow == 2) launch_mt<bf16, 2>(p, mt, amode, s);
-        else launch_mt<bf16, 1>(p, mt, amode, s);
+        if (sw_out) ok = launch_mt<bf16, 2>(p, mt, amode, s);
+        else if (wide) ok = launch_mt<bf16, 4>(p, mt, amode, s);
+        else if (nt_narrow == 2) ok = launch_mt<bf16, 2>(p, mt, amode, s);
+        else ok = launch_mt<bf16, 1>(p, mt, amode, s);
     } else {
-        if (sw_out) launch_mt<float, 2>(p, mt, amode, s);
-        else if (wide) launch_mt<float, 4>(p, mt, amode, s);
-        else if (nt_narrow == 2) launch_mt<float, 2>(p, mt, amode, s);
-        else launch_mt<float, 1>(p, mt, amode, s);
+        if (sw_out) ok = launch_mt<float, 2>(p, mt, amode, s);
+        else if (wide) ok = launch_mt<float, 4>(p, mt, amode, s);
+        else if (nt_narrow == 2) ok = launch_mt<float, 2>(p, mt, amode, s);
+        else ok = launch_mt<float, 1>(p, mt, amode, s);
     }
+    AFHIP_CHECK(ok, "afhip_gemm_skinny: internal: no kernel for %d row tiles at this width", mt);
     AFHIP_LAUNCH_CHECK();
     return 0;
 }

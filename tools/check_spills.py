@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Compiles every HIP source of the library to assembly (device side only) and lists kernels whose metadata reports spilled vector registers
+or scratch.  usage: python tools/check_spills.py [file.hip ...]   (exit code 1 if any kernel spills)"""
+import glob, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "audio-intelligence_amd", "csrc")
+extra = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "logmel.hip": ["-fno-slp-vectorize"],
+         "attention_enc.hip": ["-Wno-inline-asm", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize"],
+         "attention_enc8.hip": ["-Wno-inline-asm", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize"]}
+files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+bad = 0
+for f in files:
+    base = os.path.basename(f)
+    out = f"/tmp/spills_{base}.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S", f, "-o", out] + extra.get(base, []),
+                   check=True, stderr=subprocess.DEVNULL)
+    txt = open(out).read()
+    n = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", txt):
+        n += 1
+        name, scratch, vg, sp = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        if sp or scratch:
+            bad += 1
+            print(f"{base}: {name}: {sp} spilled VGPRs, {scratch} B scratch ({vg} VGPRs)")
+    print(f"{base}: {n} kernels checked")
+sys.exit(1 if bad else 0)
