@@ -28,7 +28,8 @@ class GemmArgs(C.Structure):
                 ("out_f32", C.c_int), ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
                 ("w_scale", C.c_void_p),
                 ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_bias", C.c_void_p), ("row_stats_out", C.c_void_p),
-                ("a_fp8", C.c_int), ("a_scale", C.c_void_p)]
+                ("a_fp8", C.c_int), ("a_scale", C.c_void_p),
+                ("a_scale_const", C.c_float), ("out_fp8", C.c_int), ("out_scale_inv", C.c_float)]
 
 
 class AttnArgs(C.Structure):
@@ -55,7 +56,8 @@ class EncoderWeights(C.Structure):
                 ("qkv_wf", c_void_pp), ("qkv_cs", c_void_pp), ("qkv_bf", c_void_pp),
                 ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp), ("q_prescaled", C.c_int),
                 ("qkv_w8", c_void_pp), ("qkv_s8", c_void_pp), ("out_w8", c_void_pp), ("out_s8", c_void_pp),
-                ("fc1_w8", c_void_pp), ("fc1_s8", c_void_pp), ("fc2_w8", c_void_pp), ("fc2_s8", c_void_pp)]
+                ("fc1_w8", c_void_pp), ("fc1_s8", c_void_pp), ("fc2_w8", c_void_pp), ("fc2_s8", c_void_pp),
+                ("fc2_in_scale", C.c_void_p), ("calib_amax", C.c_void_p)]
 
 
 class LlmWeights(C.Structure):
@@ -107,6 +109,7 @@ SIGNATURES = {
     "afhip_embed_sum": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "afhip_gather_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "afhip_quant_rows": (_I, [_P, _I, _P, _P, C.c_float, _I, _P, _P, _I, _I, _P]),
+    "afhip_absmax_bf16": (_I, [_P, C.c_longlong, _P, _P]),
     "afhip_ln_stats_finalize": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
     "afhip_row_stats": (_I, [_P, _I, _I, C.c_float, _I, _P, _P]),
     "afhip_rope_kv": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

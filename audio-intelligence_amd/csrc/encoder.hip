@@ -63,14 +63,17 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 }
 
 // e4m3 x e4m3 projection: A8 [M,K] bytes + row scales, W8 [N,K] bytes + channel scales -> bf16 C (+bias, act, +residual)
+// a_scale == NULL: every row carries a_const (statically quantised A); out_inv > 0: C leaves as e4m3 bytes = sat(value * out_inv)
 int gemm8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, const void* res, void* C,
-          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s) {
+          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s, float a_const = 0.f, float out_inv = 0.f) {
     afhip_gemm_args g = {};
     g.A = A8; g.W = W8; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = ldc; g.ldres = ldres;
     g.dtype = AFHIP_BF16; g.act = act;
     g.a_fp8 = 1; g.a_scale = a_scale; g.w_scale = w_scale;
+    g.a_scale_const = a_const;
+    g.out_fp8 = out_inv > 0.f ? 1 : 0; g.out_scale_inv = out_inv;
     return afhip_gemm(&g, s);
 }
 
@@ -194,15 +197,29 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
             } else {
                 if ((rc = gemm(att, w->out_w[l], w->out_b[l], h, h, rows, d, d, d, d, d, dt, AFHIP_ACT_NONE, 0, s))) return rc;
             }
+            // fc2's input statically quantised (afhip_encoder_weights.fc2_in_scale): fc1's epilogue writes the GELU output as e4m3 bytes into
+            // ws.big and fc2 reads them with one scale for every row -- no [rows, ffn] bf16 round trip and no quantisation launch
+            const bool fc2_static = (mask & 4) && !(mask & 8) && w->fc2_in_scale && w->fc2_in_scale[l] > 0.f;
             if (mask & 4) {
                 if ((rc = afhip_quant_rows(h, d, w->ln2_w[l], w->ln2_b[l], 1e-5f, 1, ws.ln, sc, rows, d, s))) return rc;
-                if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
+                if (fc2_static) {
+                    if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s, 0.f, 1.0f / w->fc2_in_scale[l]))) return rc;
+                } else {
+                    if ((rc = gemm8(ws.ln, sc, w->fc1_w8[l], w->fc1_s8[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, f, 0, AFHIP_ACT_GELU, s))) return rc;
+                }
             } else {
                 if ((rc = afhip_layernorm(h, w->ln2_w[l], w->ln2_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
                 if ((rc = gemm(ws.ln, w->fc1_w[l], w->fc1_b[l], nullptr, ws.big, rows, f, d, d, f, 0, dt, AFHIP_ACT_GELU, 0, s))) return rc;
             }
+            // calibration run: max |GELU output| of this layer (only meaningful while that buffer is bf16)
+            if (w->calib_amax && !fc2_static && (rc = afhip_absmax_bf16(ws.big, (long long)rows * f, w->calib_amax + l, s))) return rc;
             // fc2's input is the [rows, ffn] GELU output: a per-row quantisation pass over it (492 MB read + 246 MB written, 109 us
             // at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us) as long as that pass is a launch of its own
+            if (fc2_static) {
+                if ((rc = gemm8(ws.big, nullptr, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s, w->fc2_in_scale[l]))) return rc;
+                // the next layer's LayerNorm-folded q | k | v wants this layer's row statistics (the e4m3 form has no statistics epilogue)
+                if (qkv_fold && l + 1 < w->n_layers && (rc = afhip_row_stats(h, rows, d, 1e-5f, dt, ws.stats + (size_t)2 * rows, s))) return rc;
+            } else
             if (mask & 8) {
                 if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)
                 if ((rc = gemm8(ws.qkv, sc, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s))) return rc;

@@ -629,10 +629,12 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "afhip_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     if (a->a_fp8) {
         // e4m3 x e4m3 -> bf16 (BASELINE config 5): the persistent ping-pong kernel's F8 form is the one implementation
-        AFHIP_CHECK(a->A && a->W && a->C && a->a_scale && a->w_scale, "afhip_gemm(fp8): null operand / scale");
+        AFHIP_CHECK(a->A && a->W && a->C && (a->a_scale || a->a_scale_const > 0.f) && a->w_scale, "afhip_gemm(fp8): null operand / scale");
         AFHIP_CHECK(a->dtype == AFHIP_BF16, "afhip_gemm(fp8): output / bias / residual dtype must be bf16");
         AFHIP_CHECK(a->lda >= a->K && a->ldw >= a->K, "afhip_gemm(fp8): lda/ldw < K");
         AFHIP_CHECK(a->ldc >= (a->act == AFHIP_ACT_SWIGLU ? a->N / 2 : a->N), "afhip_gemm(fp8): ldc too small");
+        if (a->out_fp8) AFHIP_CHECK(!a->residual && !a->row_stats_out && a->act != AFHIP_ACT_SWIGLU && a->out_scale_inv > 0.f && a->ldc % 16 == 0,
+                                    "afhip_gemm(fp8): out_fp8 needs act NONE / GELU, no residual / statistics, out_scale_inv > 0, ldc %% 16 == 0");
         AFHIP_CHECK(gemm_pp_eligible(a), "afhip_gemm(fp8): needs N %% 256 == 0, K %% 256 == 0, 16-byte aligned rows (lda, ldw %% 16 == 0), bf16 out, no conv / LN fold / out_f32 (M=%d N=%d K=%d)", a->M, a->N, a->K);
         hipStream_t s8 = (hipStream_t)stream;
         const bool rec8 = g_prof.on && g_prof.n < g_prof.cap;

@@ -71,7 +71,10 @@ struct PPArgs {
     const float* ln_colsum;   // LNFOLD: [N] sum_k W'[n,k]
     const float* ln_bias;     // LNFOLD: [N] f32 bias (b + W beta)
     float* stats_out;         // STATS: [N/64][M][2] partial (sum, sum of squares) of the stored rows
-    const float* a_scale;     // F8: [M] f32 scale of each e4m3 activation row
+    const float* a_scale;     // F8: [M] f32 scale of each e4m3 activation row; NULL: a_scale_const for every row
+    float a_scale_const;
+    int out_fp8;              // F8: C is e4m3 bytes [M, ldc] = sat(value * out_inv) (afhip_gemm_args.out_fp8)
+    float out_inv;
     const float* w_scale;     // F8: [N] f32 scale of each e4m3 weight row (output channel)
     int esz;                  // operand element size in bytes: 2 (bf16) or 1 (e4m3)
 #ifdef AFHIP_PP_STAMPS
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 for (int i = 0; i < 4; ++i) {
                     const int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
                     float ra = 1.f;
-                    if constexpr (F8) ra = p.a_scale[m < p.M ? m : p.M - 1];
+                    if constexpr (F8) ra = p.a_scale ? p.a_scale[m < p.M ? m : p.M - 1] : p.a_scale_const;
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 }
                 float mean = 0.f, rstd = 1.f, asc = 1.f;
                 if constexpr (LNFOLD) { mean = st2[ha][i][0]; rstd = st2[ha][i][1]; }
-                if constexpr (F8) asc = p.a_scale[ok ? m : p.M - 1];
+                if constexpr (F8) asc = p.a_scale ? p.a_scale[ok ? m : p.M - 1] : p.a_scale_const;
                 rs[ha][i] = 0.f; rss[ha][i] = 0.f;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
@@ -627,6 +630,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                         if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
                         o[e] = (bf16)v;
                         if constexpr (STATS) { const float r = (float)o[e]; rs[ha][i] += r; rss[ha][i] = fmaf(r, r, rss[ha][i]); }
+                    }
+                    if constexpr (F8 && !HAS_RES && !STATS) {
+                        if (p.out_fp8) {
+                            // statically quantised output: the consumer's e4m3 A operand, written here instead of bf16 + a quantisation pass.
+                            // o[] (the bf16 rounding) is dead code on this path; the conversion takes the f32 values
+                            float w8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float v;
+                                v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc * wsc[hb][e], bv[hb][e]);
+                                if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
+                                w8[e] = __builtin_amdgcn_fmed3f(v * p.out_inv, -448.f, 448.f);
+                            }
+                            int lo = 0, hi = 0;
+                            lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], lo, false);
+                            lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], lo, true);
+                            hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], hi, false);
+                            hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], hi, true);
+                            if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.C) + (long long)m * p.ldc + ncol + hb * 32) = uint2{(unsigned)lo, (unsigned)hi};
+                            acc[ha][i][hb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            acc[ha][i][hb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            continue;
+                        }
                     }
                     if (ok) *reinterpret_cast<bf16x8*>(p.C + (long long)m * p.ldc + ncol + hb * 32) = o;
                     acc[ha][i][hb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -702,7 +728,8 @@ bool gemm_pp_available() { return pp_enabled(); }
 bool gemm_pp_eligible(const afhip_gemm_args* a) {
     if (a->a_fp8) {
         // e4m3 operands: this kernel is the only implementation; afhip_gemm reports what is missing when this says no
-        if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0 || !a->a_scale || !a->w_scale) return false;
+        if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0 || !(a->a_scale || a->a_scale_const > 0.f) || !a->w_scale) return false;
+        if (a->out_fp8 && (a->residual || a->act == AFHIP_ACT_SWIGLU || !(a->out_scale_inv > 0.f) || (a->ldc % 16))) return false;
         if (a->ln_stats || a->row_stats_out) return false;
         if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
         if (a->M < 1 || (a->N % PP_BN) != 0 || (a->K % 256) != 0) return false;
@@ -735,6 +762,7 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
     p.esz = a->a_fp8 ? 1 : 2;
     p.lda2 = (unsigned)(a->lda * p.esz); p.ldw2 = (unsigned)(a->ldw * p.esz);
     p.a_scale = a->a_scale; p.w_scale = a->w_scale;
+    p.a_scale_const = a->a_scale_const; p.out_fp8 = a->a_fp8 ? a->out_fp8 : 0; p.out_inv = a->out_scale_inv;
     p.ldc = a->ldc; p.ldres = a->ldres;
     p.act = a->act;
     p.tiles_m = cdiv(a->M, PP_BM); p.tiles_n = a->N / PP_BN; p.group_m = group_m;

@@ -199,6 +199,31 @@ void launch_wave_form(const bf16* x, long long ld_x, const bf16* w, const bf16* 
 
 }  // namespace
 
+// max |x| of a bf16 buffer (calibration of static activation scales): 16 B per lane per step, wave max, one atomic per wave
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const u32x4* __restrict__ x, long long n16, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4 v = x[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m = fmaxf(m, fabsf(__uint_as_float(v[e] << 16)));
+            m = fmaxf(m, fabsf(__uint_as_float(v[e] & 0xffff0000u)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+extern "C" int afhip_absmax_bf16(const void* x, long long n, float* out, void* stream) {
+    AFHIP_CHECK(x && out && n > 0 && (n % 8) == 0 && ((uintptr_t)x % 16) == 0, "afhip_absmax_bf16: needs n %% 8 == 0 and a 16-byte aligned buffer");
+    const long long n16 = n / 8;
+    const int blocks = (int)(n16 / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (unsigned*)out);
+    AFHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
                                 int rows, int D, void* stream) {
     AFHIP_CHECK(x && q && scale && rows > 0 && D > 0, "afhip_quant_rows: bad args");

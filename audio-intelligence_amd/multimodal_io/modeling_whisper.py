@@ -106,6 +106,8 @@ class AFWhisperEncoder(nn.Module):
         self._packed = None
         self._ws = None
         self._fp8 = False
+        self._fc2_in_scale = None      # per-layer static scale of fc2's e4m3 input (calibrate_fp8)
+        self._calib = None             # device [n_layers] f32: where a calibration forward records max |GELU output|
 
     def enable_fp8(self, on: bool = True):
         """BASELINE config 5: run the four projections of every layer on OCP e4m3 operands (weights quantised once per output
@@ -115,6 +117,32 @@ class AFWhisperEncoder(nn.Module):
         self._fp8 = bool(on)
         self._packed = None
         return self
+
+    @torch.no_grad()
+    def calibrate_fp8(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, margin: float = 2.0):
+        """Static quantisation of fc2's input (afhip_encoder_weights.fc2_in_scale).  Runs the e4m3 forward once on `mel_btc` with the
+        GELU output still in bf16 and records max |value| per layer on the device; scale_l = margin * amax_l / 448 (e4m3's relative
+        precision does not depend on the scale, so the margin only costs range at the small end; larger values saturate at 448).  From
+        then on fc1 writes that activation as e4m3 bytes and fc2 reads them with scale_l for every row: the [rows, ffn] bf16 round trip
+        and the per-row quantisation launch are gone.  Returns the per-layer scales.  `calibrate_fp8(None)` drops them again."""
+        if mel_btc is None:
+            self._fc2_in_scale, self._packed = None, None
+            return None
+        if not self._fp8:
+            raise L.AfhipError("calibrate_fp8: call enable_fp8() first")
+        self._fc2_in_scale = None
+        self._calib = torch.zeros(self.config.encoder_layers, dtype=torch.float32, device=self.device)
+        self._packed = None
+        self.encode_btc(mel_btc, feat_len)
+        torch.cuda.synchronize(self.device)
+        amax = self._calib.cpu()
+        self._calib = None
+        if not bool(torch.isfinite(amax).all()) or float(amax.min()) <= 0.0:
+            self._packed = None
+            raise L.AfhipError(f"calibrate_fp8: unusable activation maxima {amax.tolist()}")
+        self._fc2_in_scale = (amax * (margin / 448.0)).to(torch.float32).contiguous()
+        self._packed = None
+        return self._fc2_in_scale.clone()
 
     # ---------------------------------------------------------------- checkpoints
     @classmethod
@@ -242,6 +270,13 @@ class AFWhisperEncoder(nn.Module):
             arrays[n] = L.ptr_array(lists[n])
             setattr(w, n, C.cast(arrays[n], L.c_void_pp))
         w.lnf_w, w.lnf_b = P(self.layer_norm.weight).data_ptr(), P(self.layer_norm.bias).data_ptr()
+        if self._fp8 and dt == torch.bfloat16:
+            if self._fc2_in_scale is not None:
+                keep.append(self._fc2_in_scale)                    # HOST array: the library reads it while it builds the launches
+                w.fc2_in_scale = self._fc2_in_scale.data_ptr()
+            if self._calib is not None:
+                keep.append(self._calib)
+                w.calib_amax = self._calib.data_ptr()
         from .. import torch_ops
         self._packed = SimpleNamespace(w=w, keep=keep, arrays=arrays, blob=torch_ops.weights_blob(w))
         return self._packed

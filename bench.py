@@ -645,18 +645,34 @@ def main():
         # e4m3 operands (afhip_gemm a_fp8: block-scaled MFMA, 2x the bf16 rate; activations quantised per row, LayerNorm fused)
         ref_out = enc.encode_btc(mel)
         enc.enable_fp8(True)
-        out8 = enc.encode_btc(mel)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(3):
-            enc.encode_btc(mel)
-        ev1.record()
-        torch.cuda.synchronize()
-        enc8_ms = ev0.elapsed_time(ev1) / 3
-        d8 = (out8.float() - ref_out.float()).abs()
+
+        def fp8_leg():
+            o = enc.encode_btc(mel)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(3):
+                enc.encode_btc(mel)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / 3
+            dd = (o.float() - ref_out.float()).abs()
+            return ms, float(dd.max()), float(dd.mean())
+
+        dyn_ms, dyn_max, dyn_mean = fp8_leg()
+        # fc2's input statically quantised in fc1's epilogue: calibrated on a DIFFERENT synthetic batch than the one timed
+        gcal = torch.Generator(device=device).manual_seed(77)
+        enc.calibrate_fp8((torch.randn((4, 3000, 128), generator=gcal, device=device) * 0.5).to(torch.bfloat16))
+        enc8_ms, st_max, st_mean = fp8_leg()
+        enc.calibrate_fp8(None)
+        out8 = d8 = None
         enc8 = {"encoder_ms": enc8_ms, "encoder_audio_s_per_s": B * 30.0 / (enc8_ms * 1e-3), "speedup_vs_bf16": enc_ms / enc8_ms,
-                "vs_bf16_output_max_abs": float(d8.max()), "vs_bf16_output_mean_abs": float(d8.mean()),
-                "what": "e4m3 x e4m3 MFMA GEMMs for qkv / out / fc1 (per-row activation scales from a fused LayerNorm + quantise pass, per-channel weight scales, f32 accumulate); fc2, the residual stream and attention stay bf16"}
+                "vs_bf16_output_max_abs": st_max, "vs_bf16_output_mean_abs": st_mean,
+                "dynamic_scales_only": {"encoder_ms": dyn_ms, "speedup_vs_bf16": enc_ms / dyn_ms, "vs_bf16_output_max_abs": dyn_max, "vs_bf16_output_mean_abs": dyn_mean,
+                                        "what": "out-proj + fc1 on e4m3 operands, every activation quantised per row by its own pass; fc2 bf16"},
+                "what": "e4m3 x e4m3 MFMA GEMMs for out-proj, fc1 and fc2 (per-channel weight scales, f32 accumulate). out-proj / fc1 inputs: per-row scales from a quantise pass "
+                        "(LayerNorm fused for fc1); fc2 input: written as e4m3 by fc1's GELU epilogue with a per-layer static scale from AFWhisperEncoder.calibrate_fp8 "
+                        "(margin 2 x the calibration batch's max). q | k | v (LayerNorm-folded), attention and the residual stream stay bf16: with q | k | v in e4m3 the "
+                        "token-level contract of tests/test_gpu_config5.py fails"}
         enc.enable_fp8(False)
         del ref_out, out8, d8
         # BASELINE config 2, second run: the same 32 clips with mixed 5-30 s lengths in the self-test convention

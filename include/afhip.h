@@ -106,6 +106,14 @@ typedef struct {
      * MFMA rate).  Needs N % 256 == 0, K % 256 == 0, lda / ldw % 16 == 0; bias / GELU / residual / SWIGLU epilogues as for bf16. */
     int a_fp8;
     const float* a_scale;
+    /* a_fp8 only.  a_scale == NULL: every row of A carries the ONE scale a_scale_const (> 0) -- activations that a producer's
+     * epilogue quantised statically (out_fp8 below) instead of afhip_quant_rows's per-row pass. */
+    float a_scale_const;
+    /* a_fp8 only, act NONE or GELU, no residual / row statistics: out_fp8 != 0 writes C as OCP e4m3 BYTES [M, ldc] (ldc in bytes,
+     * % 16 == 0) instead of bf16: each value is multiplied by out_scale_inv (= 1 / the scale its consumer will pass as
+     * a_scale_const), clamped to +-448 and rounded to nearest even.  This is the fused form of "GEMM -> bf16 -> afhip_quant_rows". */
+    int out_fp8;
+    float out_scale_inv;
 } afhip_gemm_args;
 int afhip_gemm(const afhip_gemm_args* args, void* stream);
 
@@ -146,6 +154,9 @@ int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float 
  * scale [rows] f32.  D % 8 == 0, D <= 20480. */
 int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
                      int rows, int D, void* stream);
+/* Calibration helper for statically quantised activations (afhip_encoder_weights.fc2_in_scale): max |x| over n bf16 values
+ * (n % 8 == 0, x 16-byte aligned), merged into *out with an atomic max on the float's bit pattern -- the caller zeroes *out. */
+int afhip_absmax_bf16(const void* x, long long n, float* out, void* stream);
 int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream);
 int afhip_row_stats(const void* x, int rows, int D, float eps, int dtype, float* stats, void* stream);
 /* Row gather of the AF3 / Qwen2-Audio placeholder merge: replaces the three index_put / masked assignments of
@@ -258,6 +269,13 @@ typedef struct {
     const void* const* out_w8; const float* const* out_s8;
     const void* const* fc1_w8; const float* const* fc1_s8;
     const void* const* fc2_w8; const float* const* fc2_s8;
+    /* optional, e4m3 mode only.  fc2_in_scale (HOST array, [n_layers] f32, all > 0): static scale of fc2's input (the GELU output) per
+     * layer; when present fc1's epilogue writes that activation as e4m3 directly (afhip_gemm_args.out_fp8) and fc2 runs on e4m3
+     * operands with a_scale_const -- no [rows, ffn] bf16 round trip, no per-row quantisation pass.  Values come from calibration:
+     * calib_amax (DEVICE array, [n_layers] f32, zeroed by the caller) makes a forward record max |GELU output| of every layer there
+     * (python: AFWhisperEncoder.calibrate_fp8).  Either may be NULL. */
+    const float* fc2_in_scale;
+    float* calib_amax;
 } afhip_encoder_weights;
 size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 /* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);
