@@ -114,6 +114,14 @@ __device__ __forceinline__ float erf_as(float x) {
 template <typename T> __device__ __forceinline__ float gelu_act(float x);
 template <> __device__ __forceinline__ float gelu_act<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_act<bf16>(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// GELU for the e4m3-operand GEMM epilogues ONLY (no reference counterpart; their contract is the token-level one of tests/test_gpu_config5.py):
+// the tanh form x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3)), 5 VALU + exp2 + rcp instead of 11 + 2.  |error| <= 5e-4 against the erf form --
+// two orders of magnitude below an e4m3 step of the value it feeds, but above a bf16 ulp near zero, so the bf16 path never uses it.
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+    const float u = x * x;
+    const float t = x * fmaf(u, -0.044715f * 1.5957691216f * 1.4426950409f, -1.5957691216f * 1.4426950409f);   // -2 sqrt(2/pi) (x + c x^3) log2(e)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
 // a*ca + b*sb with THREE roundings (two products, one sum), never contracted into an FMA: the rotate-half RoPE of
 // modeling_qwen2.py:133-134 (q * cos + rotate_half(q) * sin as separate tensor ops).  __fmul_rn / __fadd_rn are plain
 // operators in HIP and -ffp-contract=fast fuses them (v_fma_f32 in the f32 kernels), which is 1 ulp away from the reference

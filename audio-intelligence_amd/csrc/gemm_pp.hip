@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                         if constexpr (LNFOLD) v = fmaf(rstd, fmaf(-mean, cv[hb][e], acc[ha][i][hb][e >> 2][e & 3]), bv[hb][e]);
                         else if constexpr (F8) v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc * wsc[hb][e], bv[hb][e]);
                         else v = acc[ha][i][hb][e >> 2][e & 3] + bv[hb][e];
-                        if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
+                        if constexpr (ACT == AFHIP_ACT_GELU) v = F8 ? gelu_tanh_fast(v) : gelu_act<bf16>(v);
                         if constexpr (HAS_RES) v += (float)r8[ha][i][hb][e];
                         o[e] = (bf16)v;
                         if constexpr (STATS) { const float r = (float)o[e]; rs[ha][i] += r; rss[ha][i] = fmaf(r, r, rss[ha][i]); }
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                             for (int e = 0; e < 8; ++e) {
                                 float v;
                                 v = fmaf(acc[ha][i][hb][e >> 2][e & 3], asc * wsc[hb][e], bv[hb][e]);
-                                if constexpr (ACT == AFHIP_ACT_GELU) v = gelu_act<bf16>(v);
+                                if constexpr (ACT == AFHIP_ACT_GELU) v = F8 ? gelu_tanh_fast(v) : gelu_act<bf16>(v);
                                 w8[e] = __builtin_amdgcn_fmed3f(v * p.out_inv, -448.f, 448.f);
                             }
                             int lo = 0, hi = 0;

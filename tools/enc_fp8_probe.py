@@ -8,9 +8,11 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 enc = bench.build_encoder(dev, torch.bfloat16, None)
 mode = os.environ.get("PROBE_MODE", "fp8")
-enc.enable_fp8(mode == "fp8")
+enc.enable_fp8(mode in ("fp8", "fp8static"))
 g = torch.Generator(device=dev).manual_seed(0)
 mel = (torch.randn((32, 3000, 128), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+if mode == "fp8static":
+    enc.calibrate_fp8((torch.randn((4, 3000, 128), generator=g, device=dev) * 0.5).to(torch.bfloat16))   # PROBE_MODE=fp8static: fc2 input quantised in fc1's epilogue
 for _ in range(2):
     enc.encode_btc(mel)
 torch.cuda.synchronize()
