@@ -65,7 +65,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 // e4m3 x e4m3 projection: A8 [M,K] bytes + row scales, W8 [N,K] bytes + channel scales -> bf16 C (+bias, act, +residual)
 // a_scale == NULL: every row carries a_const (statically quantised A); out_inv > 0: C leaves as e4m3 bytes = sat(value * out_inv)
 int gemm8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, const void* res, void* C,
-          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s, float a_const = 0.f, float out_inv = 0.f) {
+          int M, int N, int K, int ldc, int ldres, int act, hipStream_t s, float a_const = 0.f, float out_inv = 0.f, float* row_stats_out = nullptr) {
     afhip_gemm_args g = {};
     g.A = A8; g.W = W8; g.bias = bias; g.residual = res; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -74,6 +74,7 @@ int gemm8(const void* A8, const float* a_scale, const void* W8, const float* w_s
     g.a_fp8 = 1; g.a_scale = a_scale; g.w_scale = w_scale;
     g.a_scale_const = a_const;
     g.out_fp8 = out_inv > 0.f ? 1 : 0; g.out_scale_inv = out_inv;
+    g.row_stats_out = row_stats_out;
     return afhip_gemm(&g, s);
 }
 
@@ -216,9 +217,11 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
             // fc2's input is the [rows, ffn] GELU output: a per-row quantisation pass over it (492 MB read + 246 MB written, 109 us
             // at B = 32) costs more than the e4m3 GEMM saves (273 -> 206 us) as long as that pass is a launch of its own
             if (fc2_static) {
-                if ((rc = gemm8(ws.big, nullptr, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s, w->fc2_in_scale[l]))) return rc;
-                // the next layer's LayerNorm-folded q | k | v wants this layer's row statistics (the e4m3 form has no statistics epilogue)
-                if (qkv_fold && l + 1 < w->n_layers && (rc = afhip_row_stats(h, rows, d, 1e-5f, dt, ws.stats + (size_t)2 * rows, s))) return rc;
+                // ... with the row-statistics epilogue the next layer's LayerNorm-folded q | k | v reads (as the bf16 fc2 has)
+                const bool want_stats = qkv_fold && l + 1 < w->n_layers;
+                if ((rc = gemm8(ws.big, nullptr, w->fc2_w8[l], w->fc2_s8[l], w->fc2_b[l], h, h, rows, d, f, d, d, AFHIP_ACT_NONE, s, w->fc2_in_scale[l], 0.f,
+                                want_stats ? ws.part : nullptr))) return rc;
+                if (want_stats && (rc = afhip_ln_stats_finalize(ws.part, P, rows, d, 1e-5f, ws.stats + (size_t)2 * rows, s))) return rc;
             } else
             if (mask & 8) {
                 if ((rc = afhip_quant_rows(ws.big, f, nullptr, nullptr, 0.f, 0, ws.qkv, sc, rows, f, s))) return rc;     // [rows, f] bytes fit the idle qkv buffer (3 d x 2 B)

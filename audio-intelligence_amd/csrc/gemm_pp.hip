@@ -730,7 +730,8 @@ bool gemm_pp_eligible(const afhip_gemm_args* a) {
         // e4m3 operands: this kernel is the only implementation; afhip_gemm reports what is missing when this says no
         if (a->dtype != AFHIP_BF16 || a->conv_C > 0 || a->out_f32 || a->res_row_mod > 0 || !(a->a_scale || a->a_scale_const > 0.f) || !a->w_scale) return false;
         if (a->out_fp8 && (a->residual || a->act == AFHIP_ACT_SWIGLU || !(a->out_scale_inv > 0.f) || (a->ldc % 16))) return false;
-        if (a->ln_stats || a->row_stats_out) return false;
+        if (a->ln_stats) return false;
+        if (a->row_stats_out && (a->act != AFHIP_ACT_NONE || !a->bias || !a->residual || a->out_fp8)) return false;   // the fc2 form only
         if (a->act == AFHIP_ACT_SWIGLU && (a->bias || a->residual)) return false;
         if (a->M < 1 || (a->N % PP_BN) != 0 || (a->K % 256) != 0) return false;
         if ((a->lda % 16) || (a->ldw % 16) || (a->ldc % 8) || ((uintptr_t)a->A % 16) || ((uintptr_t)a->W % 16) || ((uintptr_t)a->C % 16)) return false;
@@ -783,7 +784,8 @@ int gemm_pp_launch(const afhip_gemm_args* a, int group_m, hipStream_t s) {
             else if (hr) pp_launch_t<AFHIP_ACT_GELU, false, true, false, false, true>(p, grid, s);
             else pp_launch_t<AFHIP_ACT_GELU, false, false, false, false, true>(p, grid, s);
         } else {
-            if (hb && hr) pp_launch_t<AFHIP_ACT_NONE, true, true, false, false, true>(p, grid, s);
+            if (hb && hr && a->row_stats_out) pp_launch_t<AFHIP_ACT_NONE, true, true, false, true, true>(p, grid, s);
+            else if (hb && hr) pp_launch_t<AFHIP_ACT_NONE, true, true, false, false, true>(p, grid, s);
             else if (hb) pp_launch_t<AFHIP_ACT_NONE, true, false, false, false, true>(p, grid, s);
             else if (hr) pp_launch_t<AFHIP_ACT_NONE, false, true, false, false, true>(p, grid, s);
             else pp_launch_t<AFHIP_ACT_NONE, false, false, false, false, true>(p, grid, s);

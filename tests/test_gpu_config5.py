@@ -443,7 +443,7 @@ def test_gemm_fp8_static_output_and_constant_row_scale():
     x8, xs = quantize_rows_e4m3(x)
     w18, w1s = quantize_rows_e4m3(w1)
 
-    def gemm8(A8, a_scale, W8, w_scale, bias, out, N, K, act, a_const=0.0, out_inv=0.0, res=None):
+    def gemm8(A8, a_scale, W8, w_scale, bias, out, N, K, act, a_const=0.0, out_inv=0.0, res=None, stats=None):
         a = L.GemmArgs()
         a.A, a.W, a.C = A8.data_ptr(), W8.data_ptr(), out.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
@@ -455,6 +455,7 @@ def test_gemm_fp8_static_output_and_constant_row_scale():
         a.a_scale = a_scale.data_ptr() if a_scale is not None else None
         a.w_scale = w_scale.data_ptr()
         a.a_scale_const, a.out_fp8, a.out_scale_inv = float(a_const), int(out_inv > 0), float(out_inv)
+        a.row_stats_out = stats.data_ptr() if stats is not None else None
         L.check(L.lib().afhip_gemm(C.byref(a), L.stream_ptr()))
 
     ref = torch.empty(M, f, dtype=torch.bfloat16, device=DEV)
@@ -485,6 +486,16 @@ def test_gemm_fp8_static_output_and_constant_row_scale():
     gemm8(q, torch.full((M,), s, dtype=torch.float32, device=DEV), w28, w2s, b2, o2, d, f, L.ACT_NONE, res=res)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+    # (3) the row-statistics epilogue of the e4m3 form (fc2 -> the next layer's LayerNorm-folded q | k | v): same output bits, and the
+    # [N/64][M] partial (sum, sum of squares) add up to the statistics of the rows that were stored
+    o3 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    part = torch.zeros(d // 64, M, 2, dtype=torch.float32, device=DEV)
+    gemm8(q, None, w28, w2s, b2, o3, d, f, L.ACT_NONE, a_const=s, res=res, stats=part)
+    torch.cuda.synchronize()
+    assert torch.equal(o3, o1)
+    tot = part.sum(dim=0)
+    assert torch.allclose(tot[:, 0], o1.float().sum(dim=1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1], o1.float().pow(2).sum(dim=1), rtol=1e-4, atol=1e-2)
     # and against fp32 arithmetic on the dequantised operands
     want = (q.view(torch.float8_e4m3fn).float() * s) @ (w28.view(torch.float8_e4m3fn).float() * w2s[:, None]).t() + b2.float() + res.float()
     err = (o1.float() - want).abs()
