@@ -163,7 +163,11 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
                            two-DMA LOAD section of phase 2 outlasts the partner's MFMA section.
                         2: schedule 0 with K half 0 of the next tile's A0 fragments read in phase 3 (A0 is the one half-tile with a spare
                            phase of DMA slack, so its landing wait moves to phase 2): reads 8 / 4 / 8 / 4.  +1.5-3 % on qkv / out / fc1+gelu,
-                           fc1 plain and fc2 unchanged; bf16 only (the e4m3 form reads both K halves as one operand and keeps 0) */
+                           fc1 plain and fc2 unchanged; bf16 only (the e4m3 form reads both K halves as one operand and keeps 0)
+                        3: TWO phases of 32 MFMAs per K tile (A0 x all columns, A1 x all columns), LOAD sections closed by lgkmcnt(0) so a slot
+                           is refilled the phase after its read: half the barriers of 0 / 2, same DMA lookahead.  Correct (same tests) and
+                           NOT faster: qkv +-3 % run to run, fc2 0.515 -> 0.528 ms, headline step 71.6 -> 72.1 ms on one box.  With the card at
+                           its 1400 W cap (profiles/r03_clock_power_probe.txt) a denser matrix stream is paid back in clock */
 #endif
 #define PP_WAIT_VM10() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
 #define PP_BARRIER()                              \
@@ -243,6 +247,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     // ... except in the two forms whose epilogue (bias + residual + row statistics, or + GELU) already needs all 256 registers: the 16
     // fragment registers that then stay live across it spill 7-24 VGPRs, and fc2 (the statistics form) gained nothing from the schedule
     constexpr bool EARLY_A0 = PP_SCHED == 2 && !F8 && !(HAS_BIAS && HAS_RES && (STATS || ACT == AFHIP_ACT_GELU));
+    // PP_SCHED 3: TWO phases of 32 MFMAs per K tile instead of four of 16 -- half the barriers (bf16 form only)
+    constexpr bool TWO_PHASE = PP_SCHED == 3 && !F8;
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef int v8i_t __attribute__((ext_vector_type(8)));
     const int unit_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte: block scales off
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #if PP_SCHED == 1
     pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_STAGE + PP_OFF_B1);
 #endif
+    if constexpr (TWO_PHASE) pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_STAGE + PP_OFF_B1);
     c2 = c1;
     pp_cur_advance(p, c2, n_my);                  // stream tile 2
 #if PP_SCHED == 1
@@ -381,6 +388,53 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         auto dma1 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
         auto dma2 = [&]() { pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0); };
         auto dma3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0); };
+        if constexpr (TWO_PHASE) {
+            // phase 0: A rows 0-127 (A0) x all 256 columns; phase 1: A rows 128-255 (A1).  Every LOAD section ends with lgkmcnt(0) in front of
+            // its barrier, so a slot is free for refill as soon as both groups have passed the barrier after reading it: A1 of the other
+            // stage (read in phase 1 of the previous K tile) is refilled in phase 0, A0 B0 B1 of this stage (read in phase 0) in phase 1.
+            // Stream order ... A1(t+1) | A0 B0 B1 (t+2) | A1(t+2) | ...: every counted wait leaves 4 half-tiles (8 instructions) in flight.
+            auto mfma_half = [&](auto ha_tag) {
+                constexpr int HA = decltype(ha_tag)::value;
+#if PP_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[HA][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][kk], fa[i][kk], acc[HA][i][0][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[HA][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][kk], fa[i][kk], acc[HA][i][1][j], 0, 0, 0);
+                    }
+#if PP_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            };
+            // phase 0
+            read_b(st + PP_OFF_B0, fb0);
+            read_b(st + PP_OFF_B1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(st + PP_OFF_A0);
+            pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1);
+            PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 (t+1), A1(t+1) in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mfma_half(I0{});
+            PP_BARRIER();
+            // phase 1
+            read_a(st + PP_OFF_A1);
+            pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0);
+            pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0);
+            pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[1][0], voffB[1][1], d_same + PP_OFF_B1);
+            PP_WAIT_VM8();                            // A0 B0 B1 (t+1) landed; A1(t+1), A0 B0 B1 (t+2) in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mfma_half(I1{});
+            PP_BARRIER();
+        } else {
 #if PP_SCHED == 1
         // issue order of a K tile: A1(t+1) | - | A0(t+2) B0(t+2) | B1(t+2); in the stream that is the natural order A0 B0 B1 A1 of
         // every tile, so each counted wait below leaves exactly the younger half-tiles (2 instructions each) in flight
@@ -488,6 +542,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_BARRIER();
         PP_STAMP();
 #endif
+        }
         c1 = c2;
         pp_cur_advance(p, c2, n_my);
     };
