@@ -153,12 +153,24 @@ def delay_deinterleave(codes: torch.Tensor) -> torch.Tensor:
 class DiscreteAudioTokenIO(AbsIO):
     """The part of DiscreteAudioIO the LLM side depends on: `num_stream` codebook streams of `codebook_size` entries (+1 pad id
     each, audio.py:301-414), their vocabulary and stream intervals, and `decode_batch` up to the codec call: unified-vocabulary
-    ids [B, T, S] -> de-interleaved codec codes [B, T - S + 1, S] (audio.py:494-541).  No codec model: `decode_batch` returns codes."""
+    ids [B, T, S] -> de-interleaved codec codes [B, T - S + 1, S] (audio.py:494-541).  Without a codec model `decode_batch` returns the
+    codes; with one attached (`attach_codec`: the reference's `codec_choice == "Xcodec"` object, `transformers.XcodecModel`, which the
+    reference fetches by tag, audio.py:203-218) it finishes the reference's method -- `_codec_decode_batch`, audio.py:573-588 -- and returns
+    (audio [B, 1, samples], sample lengths, sample_rate).  The codec network itself is the caller's HF module and runs where it lives; it
+    is not part of the HIP path."""
 
     def __init__(self, n_stream: int = 8, codebook_size: int = 1024, delay_interleave: bool = True):
         super().__init__(modality="audio", is_discrete=True)
         self.n_stream, self.codebook_size, self.delay = n_stream, codebook_size, delay_interleave
         self._stream_intervals = None
+        self.codec_model, self.sample_rate, self.frame_shift = None, None, None
+
+    def attach_codec(self, codec_model):
+        """audio.py:203-218: the X-codec object and the two facts the IO takes from its config."""
+        self.codec_model = codec_model
+        self.sample_rate = codec_model.config.sample_rate
+        self.frame_shift = codec_model.config.hop_length
+        return self
 
     def num_stream(self):
         return self.n_stream
@@ -186,4 +198,12 @@ class DiscreteAudioTokenIO(AbsIO):
         codes = codes.clone()
         for s, (start, _) in enumerate(self.get_stream_interval()):
             codes[..., s] -= start + 1                  # ids relative to the IO's own vocabulary; slot 0 of a stream is its pad
-        return codes, lengths
+        if self.codec_model is None:
+            return codes, lengths
+        # audio.py:573-588 (_codec_decode_batch, Xcodec branch): [B, T, S] -> [B, S, T], pad ids (-1) decode as entry 0
+        c = codes.permute(0, 2, 1)
+        c = torch.where(c < 0, torch.zeros_like(c), c)
+        audio = self.codec_model.decode(c).audio_values
+        if audio.dim() == 2:
+            audio = audio.unsqueeze(1)
+        return audio, lengths * self.frame_shift, self.sample_rate

@@ -283,3 +283,35 @@ def test_torch_library_ops_registered_with_meta_kernels():
     import pytest
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.afhip.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-6)
+
+
+def test_discrete_audio_decode_batch_through_an_offline_xcodec():
+    """`transformers.XcodecModel` DOES construct offline from its default config (16 kHz, hop 320, codebooks of
+    1024; the reference fetches trained weights by tag, audio.py:203-218 -- here seeded random ones).  With it attached,
+    DiscreteAudioTokenIO.decode_batch finishes the reference's decode_batch (audio.py:494-541 + _codec_decode_batch 573-588): delay
+    de-interleave, vocabulary offsets removed, pad ids (-1) decoded as entry 0, [B, S, T] into codec.decode, lengths x hop.  The expected
+    waveform is the same codec called directly on the codes.  CPU on purpose: the codec network is the caller's HF module, not HIP code."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "XcodecModel"):
+        pytest.skip("transformers without XcodecModel")
+    from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO, delay_interleave
+    torch.manual_seed(0)
+    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval()
+    assert codec.config.sample_rate == 16000 and codec.config.hop_length == 320 and codec.config.codebook_size == 1024
+    io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
+    g = torch.Generator().manual_seed(1)
+    B, T = 2, 12
+    codes = torch.randint(0, 1024, (B, T, 8), generator=g)
+    codes[1, -3:, :] = -1                                                   # a shorter clip: its tail holds pad entries
+    rel = torch.stack([codes[..., s] + s * 1025 + 1 for s in range(8)], dim=-1)          # ids inside the IO's vocabulary (slot 0 = pad)
+    inter = delay_interleave(rel, [s * 1025 for s in range(8)])
+    with torch.no_grad():
+        audio, alen, sr = io.decode_batch(inter, torch.tensor([T + 7, T + 7 - 3]))
+        want = codec.decode(torch.where(codes < 0, torch.zeros_like(codes), codes).permute(0, 2, 1)).audio_values
+    assert sr == 16000 and alen.tolist() == [T * 320, (T - 3) * 320]
+    assert audio.shape == (B, 1, T * 320) and bool(torch.isfinite(audio).all())
+    assert torch.equal(audio, want)
+    # without a codec the method still stops at the codes (what the GPU generation tests pin against the reference's golden file)
+    back, lens = DiscreteAudioTokenIO().decode_batch(inter, torch.tensor([T + 7, T + 7]))
+    assert torch.equal(back, codes) and lens.tolist() == [T, T]
