@@ -441,10 +441,16 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 constexpr int PAR = IDX & 1, NXT = PAR ^ 1;
                 // tile t+1 must have landed before its K fragments are read in slot 1; tile t+2 (4 DMA instructions) may stay in flight
                 E_STAMP(0);                                    // 0: tile starts
+#ifdef E_TIMING_HALFSYNC   /* TIMING EXPERIMENT ONLY (races): what one DMA wait + barrier per TWO tiles would buy at most */
+                if (!(t & 1)) {
+#endif
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 E_STAMP(1);                                    // 1: tile t+1 landed (this wave's part)
                 E_BARRIER();
+#ifdef E_TIMING_HALFSYNC
+                }
+#endif
                 E_STAMP(2);                                    // 2: barrier passed
                 if (t + 3 < nt) dma_tile(cur, t + 3);          // stage (t+3)&3 = (t-1)&3: last read (V(t-1)) before the barrier above
                 E_FENCE();
