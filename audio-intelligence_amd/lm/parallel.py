@@ -372,9 +372,18 @@ class ParallelLLM(nn.Module):
     @torch.no_grad()
     def _embed(self, input_ids, kwargs):
         """lm/parallel.py:219-284: stream-summed token embeddings, continuous features spliced in through the adaptor."""
+        # (1) discrete modalities handed over as raw features: tokenise on the fly and place the ids (lm/parallel.py:233-257).  The IO
+        #     needs a tokeniser of its own (DiscreteAudioTokenIO.attach_codec); without one its encode_batch raises.
         for io_name, io in self.multimodal_io_dict.items():
-            if io.is_discrete and f"{io_name}_feats" in kwargs:
-                raise NotImplementedError("on-the-fly discrete tokenisation (lm/parallel.py:235-257) is outside the audio-understanding path")
+            if not io.is_discrete:
+                continue
+            if f"{io_name}_indices" not in kwargs or f"{io_name}_feats" not in kwargs or f"{io_name}_lengths" not in kwargs:
+                continue
+            codes = io.encode_batch(kwargs[f"{io_name}_feats"], kwargs[f"{io_name}_lengths"])
+            codes = codes + self.vocab_intervals[io_name][0][0]
+            input_ids = input_ids.clone()
+            for code, (bidx, start, length) in zip(codes, kwargs[f"{io_name}_indices"].tolist()):
+                input_ids[bidx, start: start + length] = code[:length].to(input_ids.device)
         input_embeds = ops.embed_sum(input_ids.to(self.device), self.model.embed_tokens.weight)
         for io_name, io in self.multimodal_io_dict.items():
             if io.is_discrete:

@@ -163,14 +163,59 @@ class DiscreteAudioTokenIO(AbsIO):
         super().__init__(modality="audio", is_discrete=True)
         self.n_stream, self.codebook_size, self.delay = n_stream, codebook_size, delay_interleave
         self._stream_intervals = None
-        self.codec_model, self.sample_rate, self.frame_shift = None, None, None
+        object.__setattr__(self, "codec_model", None)
+        self.sample_rate, self.frame_shift, self.codec_bandwidth = None, None, None
 
     def attach_codec(self, codec_model):
-        """audio.py:203-218: the X-codec object and the two facts the IO takes from its config."""
-        self.codec_model = codec_model
+        """audio.py:203-233: the X-codec object, the two facts the IO takes from its config, and the target bandwidth closest to
+        `n_stream` quantizers (log2(codebook) bits x frames per second each)."""
+        import math
+        # kept OUT of the module tree on purpose: the drop-in's state-dict keys stay those of the checkpoint (strict=True loads), and the
+        # codec lives on whatever device its owner put it
+        object.__setattr__(self, "codec_model", codec_model)
         self.sample_rate = codec_model.config.sample_rate
         self.frame_shift = codec_model.config.hop_length
+        per_q = math.log2(codec_model.config.codebook_size) * (self.sample_rate // self.frame_shift) / 1000      # kbps
+        want = per_q * self.n_stream
+        self.codec_bandwidth = min(codec_model.config.target_bandwidths, key=lambda x: abs(x - want))
         return self
+
+    def find_length(self, data):
+        """audio.py:656-672: frames a clip (wav [ch, samples], sample rate) becomes, delay interleave included."""
+        if self.codec_model is None:
+            raise RuntimeError("DiscreteAudioTokenIO.find_length needs a codec (attach_codec)")
+        wav, sr = data
+        num_samples = wav.shape[-1] * self.sample_rate / sr
+        return int(num_samples // self.frame_shift) + (self.n_stream - 1 if self.delay else 0)
+
+    def encode_batch(self, data: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """audio.py:417-491 for the codec-only configuration (no SSL streams: their tokeniser is not importable here):
+        wav [B, samples, channels] + sample lengths [B] -> ids [B, frames (+ n_stream - 1), n_stream] in the IO's own vocabulary
+        (stream offset + 1, slot 0 of a stream = pad), delay-interleaved.  The codec is the attached HF module (audio.py:641-654)."""
+        if self.codec_model is None:
+            raise RuntimeError("DiscreteAudioTokenIO.encode_batch needs a codec (attach_codec): on-the-fly tokenisation has no other source")
+        if data.dim() != 3:
+            raise ValueError(f"Expected 3D tensor [batch, samples, num_channel], got {data.dim()}D")
+        data = data.transpose(1, 2)
+        frame_lengths = lengths // self.frame_shift
+        lengths = frame_lengths * self.frame_shift
+        data = data[:, :, : int(lengths.max())]
+        codec_codes = self.codec_model.encode(data[:, :1, : int(lengths.max())], bandwidth=self.codec_bandwidth, return_dict=False)
+        codec_codes = codec_codes.permute(0, 2, 1)[:, :, : self.n_stream]                       # [B, T, S]
+        max_frames = int(frame_lengths.max())
+        cur = codec_codes.size(1)
+        if cur > max_frames:
+            codec_codes = codec_codes[:, :max_frames]
+        elif cur < max_frames:
+            codec_codes = torch.nn.functional.pad(codec_codes, (0, 0, 0, max_frames - cur), mode="replicate")
+        codes = codec_codes.to(torch.long).clone()
+        pads = []
+        for s, (start, _) in enumerate(self.get_stream_interval()):
+            codes[..., s] += start + 1
+            pads.append(start)
+        if self.delay:
+            codes = delay_interleave(codes, pads)
+        return codes
 
     def num_stream(self):
         return self.n_stream

@@ -174,3 +174,41 @@ def test_sample_topk_kernel_vs_oracle(dt, cfgw):
     a.k, a.temperature, a.u, a.token = 1, 1.0, None, None
     L.check(lib.afhip_sample_topk(C.byref(a), L.stream_ptr()))
     assert o_idx.view(-1)[:rows].cpu().long().tolist() == ref_mixed.float().argmax(-1).tolist()
+
+
+def test_embed_tokenises_discrete_audio_on_the_fly():
+    """lm/parallel.py:233-257 (missing #2): a batch that carries raw audio for the DISCRETE audio IO
+    (`discrete_audio_feats / _lengths / _indices`) is tokenised inside `_embed` and the ids land at (b, start, length) before the
+    stream-summed embedding.  Tokeniser = the offline X-codec attached to DiscreteAudioTokenIO (seeded random weights, on the GPU as a
+    plain torch module -- it is the reference's own dependency, not HIP code).  Expected = `_embed` on ids placed by hand."""
+    _need_gpu()
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "XcodecModel"):
+        pytest.skip("transformers without XcodecModel")
+    from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO
+    model, _ = H.build_tiny_ualm(torch.float32, DEV)
+    torch.manual_seed(0)
+    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval().to(DEV)
+    io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
+    old = model.multimodal_io_dict["discrete_audio"]
+    assert io.get_stream_interval() == old.get_stream_interval() and io.num_stream() == old.num_stream()
+    model.multimodal_io_dict["discrete_audio"] = io
+    g = torch.Generator().manual_seed(4)
+    wav = (torch.randn(1, 6400, 1, generator=g) * 0.1).to(DEV)                      # 20 frames -> 27 positions with the delay pattern
+    lengths = torch.tensor([6400])
+    T = 6400 // 320 + 7
+    base = model.vocab_intervals["discrete_audio"][0][0]
+    ids = torch.zeros(1, T + 6, 8, dtype=torch.long)
+    ids[:, :, 0] = torch.randint(0, model.vocab_intervals["text"][0][1], (1, T + 6), generator=g)
+    kw = {"discrete_audio_feats": wav, "discrete_audio_lengths": lengths, "discrete_audio_indices": torch.tensor([[0, 3, T]])}
+    got = model._embed(ids.clone(), kw)
+    with torch.no_grad():
+        codes = io.encode_batch(wav, lengths).cpu() + base
+    by_hand = ids.clone()
+    by_hand[0, 3:3 + T] = codes[0, :T]
+    want = model._embed(by_hand, {})
+    assert torch.equal(got, want)
+    assert not torch.equal(got, model._embed(ids.clone(), {}))                       # the audio ids really changed the rows
+    model.multimodal_io_dict["discrete_audio"] = DiscreteAudioTokenIO()               # no tokeniser attached: a clear error, not silence
+    with pytest.raises(RuntimeError):
+        model._embed(ids.clone(), kw)

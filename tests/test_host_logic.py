@@ -315,3 +315,36 @@ def test_discrete_audio_decode_batch_through_an_offline_xcodec():
     # without a codec the method still stops at the codes (what the GPU generation tests pin against the reference's golden file)
     back, lens = DiscreteAudioTokenIO().decode_batch(inter, torch.tensor([T + 7, T + 7]))
     assert torch.equal(back, codes) and lens.tolist() == [T, T]
+
+
+def test_discrete_audio_encode_batch_through_an_offline_xcodec():
+    """audio.py:417-491 (codec-only configuration) with the offline X-codec: wav [B, samples, 1] -> ids in the IO's vocabulary, delay
+    interleaved.  Expected = the codec called directly (audio.py:641-654: first channel, trimmed to whole frames, the target bandwidth
+    closest to 8 quantizers) + stream offsets + the delay pattern; decode_batch (without a codec) takes the ids back to the codes."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "XcodecModel"):
+        pytest.skip("transformers without XcodecModel")
+    from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO, delay_interleave
+    torch.manual_seed(0)
+    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval()
+    io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
+    assert io.codec_bandwidth == 4 and io.frame_shift == 320
+    g = torch.Generator().manual_seed(2)
+    wav = torch.randn(2, 16000 + 123, 1, generator=g) * 0.1
+    lengths = torch.tensor([16000 + 123, 9000])
+    assert io.find_length((wav[0].T.numpy(), 16000)) == (16000 + 123) // 320 + 7
+    assert io.find_length((wav[0].T.numpy(), 8000)) == int((16000 + 123) * 2 // 320) + 7
+    with torch.no_grad():
+        ids = io.encode_batch(wav, lengths)
+        T = (16000 + 123) // 320
+        direct = codec.encode(wav.transpose(1, 2)[:, :1, : T * 320], bandwidth=4, return_dict=False).permute(0, 2, 1)[:, :, :8]
+    assert direct.shape[1] == T
+    rel = torch.stack([direct[..., s].long() + s * 1025 + 1 for s in range(8)], dim=-1)
+    assert ids.shape == (2, T + 7, 8) and torch.equal(ids, delay_interleave(rel, [s * 1025 for s in range(8)]))
+    back, lens = DiscreteAudioTokenIO().decode_batch(ids, torch.tensor([T + 7, T + 7]))
+    assert torch.equal(back, direct.long()) and lens.tolist() == [T, T]
+    with pytest.raises(RuntimeError):
+        DiscreteAudioTokenIO().encode_batch(wav, lengths)
+    with pytest.raises(ValueError):
+        io.encode_batch(wav[:, :, 0], lengths)
