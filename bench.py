@@ -145,6 +145,61 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
 MEL_BYTES_PER_CLIP = 480000 * 4 + 128 * 3000 * 4      # read wav + write f32 mel
 
 
+class BoardSampler:
+    """Shader clock and board power of THIS process's GPU while the timed steps run, read from the card's own hwmon files (the card is
+    found by the PCI address torch reports for the device; a box shows every card of its host).  The 2.5 PFLOP/s peak is priced at 2.4 GHz:
+    a kernel that runs at the board's power cap is clocked lower by the firmware, and `peak_at_clock` is the matrix peak at the clock it
+    actually got (profiles/r03_clock_power_probe.txt).  Returns None where the files are not readable."""
+
+    def __init__(self, device_index):
+        import glob
+        self.freq = self.power = self.cap = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cards = [c for c in sorted(glob.glob("/sys/class/drm/card*")) if os.path.basename(os.path.realpath(c + "/device")) == bdf]
+            if cards:
+                hw = sorted(glob.glob(cards[0] + "/device/hwmon/hwmon*"))
+                if hw:
+                    self.freq = hw[0] + "/freq1_input"
+                    self.power = hw[0] + "/power1_input" if os.path.exists(hw[0] + "/power1_input") else hw[0] + "/power1_average"
+                    self.cap = hw[0] + "/power1_cap"
+        except Exception:  # noqa: BLE001 - diagnostics only
+            pass
+        self.samples, self._stop, self._th = [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append((int(open(self.freq).read()) / 1e6, int(open(self.power).read()) / 1e6))
+            except (OSError, ValueError):
+                return
+            time.sleep(0.01)
+
+    def start(self):
+        if self.freq and self.power:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop = True
+        self._th.join()
+        sm = self.samples[len(self.samples) // 5:]          # drop the ramp at the start of the timed region
+        if len(sm) < 3:
+            return None
+        mhz = sorted(x[0] for x in sm)[len(sm) // 2]
+        w = sorted(x[1] for x in sm)[len(sm) // 2]
+        try:
+            cap = int(open(self.cap).read()) / 1e6
+        except (OSError, ValueError):
+            cap = None
+        return {"shader_clock_mhz_median": mhz, "board_power_w_median": w, "board_power_cap_w": cap, "samples": len(sm),
+                "what": "hwmon freq1_input / power1_input of this GPU sampled every 10 ms over the timed steps (all kernels of the step, not the GEMM alone)"}
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (newest
     profiles/rNN_hbm_traffic_pmc.json; unit and gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  PMC passes serialise
@@ -606,11 +661,14 @@ def main():
 
     fence()
     L.check(lib.afhip_prof_enable(args.steps * (4 * ENC_CFG["encoder_layers"] + 2) + 8))
+    board = BoardSampler(device.index if device.index is not None else 0)
+    board.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    board_info = board.stop()
     fence()
     # the dominant kernel = gemm_pp_kernel (128 of the 130 GEMM launches of a forward, > 99 % of its FLOPs); the two
     # implicit-conv stem launches (gemm256_kernel) are collected separately
@@ -725,7 +783,8 @@ def main():
                          "avg_launch_gflop": fl.value / max(1, n_l.value) / 1e9, "gemm_share_of_step": ms.value / (elapsed * 1e3) if world == 1 else None,
                          "other_gemm": {"kernel": "gemm256_kernel (implicit-conv stem)", "launches": n_o.value,
                                         "avg_launch_ms": ms_o.value / max(1, n_o.value),
-                                        "tflops": fl_o.value / (ms_o.value * 1e-3) / 1e12 if ms_o.value > 0 else 0.0}},
+                                        "tflops": fl_o.value / (ms_o.value * 1e-3) / 1e12 if ms_o.value > 0 else 0.0},
+                         "board": board_info},
             "stages": {"mel_ms": mel_ms, "mel_audio_s_per_s": B * 30.0 / (mel_ms * 1e-3),
                        "mel_roofline": {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": mel_gbs / PEAK_HBM_GBS, "traffic": mel_traffic, "bytes_per_clip": MEL_BYTES_PER_CLIP},
@@ -734,6 +793,10 @@ def main():
                        "encoder_ms": enc_ms, "encoder_audio_s_per_s": B * 30.0 / (enc_ms * 1e-3),
                        "encoder_tflops": enc_flops_per_clip(ENC_CFG) * B / (enc_ms * 1e-3) / 1e12},
         }
+    if rank == 0 and res["roofline"].get("board"):
+        bi = res["roofline"]["board"]
+        bi["peak_at_clock_tflops"] = PEAK_BF16_TFLOPS * bi["shader_clock_mhz_median"] / 2400.0
+        bi["frac_at_clock"] = res["roofline"]["achieved"] / bi["peak_at_clock_tflops"]
     if do_cpu:
         cb, ref_out = cpu_baseline(cpu_state, args.cpu_clips, wav_cpu)
         err = (out[: args.cpu_clips].float().cpu() - ref_out).abs()
