@@ -41,7 +41,8 @@ class AttnArgs(C.Structure):
                 ("causal", C.c_int), ("q_pos0", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
                 ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
                 ("q_prescaled", C.c_int), ("new_k", C.c_void_p), ("new_v", C.c_void_p), ("new_kv_batch_stride", C.c_longlong),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p), ("row_off", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p), ("row_off", C.c_void_p),
+                ("out_fp8", C.c_int), ("out_scale_inv", C.c_float)]
 
 
 class EncoderWeights(C.Structure):
@@ -57,7 +58,7 @@ class EncoderWeights(C.Structure):
                 ("fc1_wf", c_void_pp), ("fc1_cs", c_void_pp), ("fc1_bf", c_void_pp), ("q_prescaled", C.c_int),
                 ("qkv_w8", c_void_pp), ("qkv_s8", c_void_pp), ("out_w8", c_void_pp), ("out_s8", c_void_pp),
                 ("fc1_w8", c_void_pp), ("fc1_s8", c_void_pp), ("fc2_w8", c_void_pp), ("fc2_s8", c_void_pp),
-                ("fc2_in_scale", C.c_void_p), ("calib_amax", C.c_void_p)]
+                ("fc2_in_scale", C.c_void_p), ("calib_amax", C.c_void_p), ("att_out_scale", C.c_void_p)]
 
 
 class LlmWeights(C.Structure):

@@ -616,6 +616,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
     if (afhip_attention_enc64x8(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
     if (afhip_attention_enc64(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
+    AFHIP_CHECK(!a->out_fp8, "afhip_attention: out_fp8 is a feature of the encoder form (bf16, head_dim 64, q_prescaled, non-causal, no key split)");
 
     AttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;

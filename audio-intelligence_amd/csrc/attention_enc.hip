@@ -62,6 +62,8 @@ struct EncAttnP {
     long long q_bs, kv_bs, o_bs;
     long long q_hs, kv_hs, o_hs;
     int n_qt, n_blk;
+    int out_fp8;                // o is e4m3 bytes = sat(value * out_inv) (afhip_attn_args.out_fp8)
+    float out_inv;
 #ifdef AFHIP_ENC_STAMPS
     unsigned long long* dbg;    // AFHIP_ENC_DBGPTR: [2][64] stamps
 #endif
@@ -532,6 +534,36 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
         const float la = l_a + __shfl_xor(l_a, 32, 64), lb = l_b + __shfl_xor(l_b, 32, 64);
         const float ia = la > 0.f ? 1.0f / la : 0.f, ib = lb > 0.f ? 1.0f / lb : 0.f;
         char* ost = smem + E_RING + wave * (64 * E_OROW);
+        if (p.out_fp8) {
+            // statically quantised output (the out-projection's e4m3 A operand): 4 values -> one dword at [query][d], rows of 64 bytes
+            static_for<0, 16>([&](auto it) {
+                constexpr int i = decltype(it)::value;                   // (block, d tile, group of 4 registers)
+                constexpr int blk = i >> 3, dt = (i >> 2) & 1, g = i & 3;
+                float o0, o1, o2, o3;
+                E_ACC_READ(o0, blk * 32 + dt * 16 + 4 * g);
+                E_ACC_READ(o1, blk * 32 + dt * 16 + 4 * g + 1);
+                E_ACC_READ(o2, blk * 32 + dt * 16 + 4 * g + 2);
+                E_ACC_READ(o3, blk * 32 + dt * 16 + 4 * g + 3);
+                const float sc = (blk ? ib : ia) * p.out_inv;
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(o0 * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(o1 * sc, -448.f, 448.f), w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(o2 * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(o3 * sc, -448.f, 448.f), w, true);
+                const int d = dt * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<int*>(ost + (blk * 32 + fr) * E_OROW + d) = w;
+            });
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + (lane >> 2), c = lane & 3;
+                const int qrow = q0 + wave * 64 + r;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(ost + r * E_OROW + c * 16);
+                if (qrow < Tq) {
+                    char* op = p.o + o_off + (long long)qrow * p.ld_o + (long long)hh * p.o_hs;      // one byte per element
+                    *reinterpret_cast<u32x4*>(op + c * 16) = val;
+                }
+            }
+        } else {
         static_for<0, 16>([&](auto it) {
             constexpr int i = decltype(it)::value;                   // (block, d tile, group of 4 registers)
             constexpr int blk = i >> 3, dt = (i >> 2) & 1, g = i & 3;
@@ -556,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 __bf16* op = reinterpret_cast<__bf16*>(p.o) + o_off + (long long)qrow * p.ld_o + (long long)hh * p.o_hs;
                 *reinterpret_cast<u32x4*>(op + c * 8) = val;
             }
+        }
         }
         if (v < 0) break;
         cur = nxt;
@@ -587,6 +620,7 @@ bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s) {
     const long long nblk = (long long)p.n_qt * a->n_q * a->B;
     if (nblk >= (1ll << 31)) return false;
     p.n_blk = (int)nblk;
+    p.out_fp8 = a->out_fp8; p.out_inv = a->out_scale_inv;
 #ifdef AFHIP_ENC_STAMPS
     { const char* e = getenv("AFHIP_ENC_DBGPTR"); p.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr; }
 #endif

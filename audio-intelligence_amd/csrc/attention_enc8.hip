@@ -460,7 +460,7 @@ bool afhip_attention_enc64x8(const afhip_attn_args* a, hipStream_t s) {
     // the half-tile rotation) -- the SIMD's issue port, not the overlap of VALU and matrix bursts, is what both forms run into.  AFHIP_ATTN_ENC8=1 selects it.
     { const char* e = getenv("AFHIP_ATTN_ENC8"); if (!(e && e[0] == '1')) return false; }   // read per call
     if (a->dtype != AFHIP_BF16 || a->hd != 64 || !a->q_prescaled || a->causal || a->key_split > 0 || a->n_q != a->n_kv || a->Tq != a->Tk) return false;
-    if (a->new_k || a->seq_pos) return false;
+    if (a->new_k || a->seq_pos || a->out_fp8) return false;
     if ((long long)a->Tk * a->ld_kv * 2 >= (1ll << 31)) return false;      // 32-bit DMA offsets inside one (clip, head)
     EncAttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;

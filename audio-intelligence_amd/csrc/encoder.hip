@@ -191,8 +191,16 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
                 if ((rc = afhip_layernorm(h, w->ln1_w[l], w->ln1_b[l], ws.ln, rows, d, 1e-5f, dt, s))) return rc;
                 if ((rc = gemm(ws.ln, w->qkv_w[l], w->qkv_b[l], nullptr, ws.qkv, rows, 3 * d, d, d, 3 * d, 0, dt, AFHIP_ACT_NONE, 0, s))) return rc;
             }
+            // attention output statically quantised (afhip_encoder_weights.att_out_scale): the attention kernel writes e4m3 bytes into `att`
+            // and the out-projection reads them with one scale for every row -- no bf16 round trip, no quantisation launch.  Needs the
+            // encoder attention form, i.e. the prescaled q of the LayerNorm-folded q | k | v GEMM
+            const bool att_static = (mask & 2) && a.q_prescaled && hd == 64 && w->att_out_scale && w->att_out_scale[l] > 0.f;
+            if (att_static) { a.out_fp8 = 1; a.out_scale_inv = 1.0f / w->att_out_scale[l]; }
             if ((rc = afhip_attention(&a, s))) return rc;
-            if (mask & 2) {
+            if (w->calib_amax && !att_static && (rc = afhip_absmax_bf16(att, (long long)rows * d, w->calib_amax + w->n_layers + l, s))) return rc;
+            if (att_static) {
+                if ((rc = gemm8(att, nullptr, w->out_w8[l], w->out_s8[l], w->out_b[l], h, h, rows, d, d, d, d, AFHIP_ACT_NONE, s, w->att_out_scale[l]))) return rc;
+            } else if (mask & 2) {
                 if ((rc = afhip_quant_rows(att, d, nullptr, nullptr, 0.f, 0, ws.ln, sc, rows, d, s))) return rc;
                 if ((rc = gemm8(ws.ln, sc, w->out_w8[l], w->out_s8[l], w->out_b[l], h, h, rows, d, d, d, d, AFHIP_ACT_NONE, s))) return rc;
             } else {

@@ -107,6 +107,7 @@ class AFWhisperEncoder(nn.Module):
         self._ws = None
         self._fp8 = False
         self._fc2_in_scale = None      # per-layer static scale of fc2's e4m3 input (calibrate_fp8)
+        self._att_out_scale = None     # per-layer static scale of the attention output = the out-projection's e4m3 input
         self._calib = None             # device [n_layers] f32: where a calibration forward records max |GELU output|
 
     def enable_fp8(self, on: bool = True):
@@ -119,28 +120,32 @@ class AFWhisperEncoder(nn.Module):
         return self
 
     @torch.no_grad()
-    def calibrate_fp8(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, margin: float = 2.0):
+    def calibrate_fp8(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, margin: float = 2.0, attention_output: bool = True):
         """Static quantisation of fc2's input (afhip_encoder_weights.fc2_in_scale).  Runs the e4m3 forward once on `mel_btc` with the
         GELU output still in bf16 and records max |value| per layer on the device; scale_l = margin * amax_l / 448 (e4m3's relative
         precision does not depend on the scale, so the margin only costs range at the small end; larger values saturate at 448).  From
         then on fc1 writes that activation as e4m3 bytes and fc2 reads them with scale_l for every row: the [rows, ffn] bf16 round trip
-        and the per-row quantisation launch are gone.  Returns the per-layer scales.  `calibrate_fp8(None)` drops them again."""
+        and the per-row quantisation launch are gone.  `attention_output=True` does the same for the attention output -> out-projection
+        (the encoder attention kernel writes e4m3).  Returns the fc2 scales.  `calibrate_fp8(None)` drops everything again."""
         if mel_btc is None:
-            self._fc2_in_scale, self._packed = None, None
+            self._fc2_in_scale, self._att_out_scale, self._packed = None, None, None
             return None
         if not self._fp8:
             raise L.AfhipError("calibrate_fp8: call enable_fp8() first")
-        self._fc2_in_scale = None
-        self._calib = torch.zeros(self.config.encoder_layers, dtype=torch.float32, device=self.device)
+        self._fc2_in_scale, self._att_out_scale = None, None
+        nl = self.config.encoder_layers
+        self._calib = torch.zeros(2 * nl, dtype=torch.float32, device=self.device)      # [0, nl): max |GELU output|; [nl, 2 nl): max |attention output|
         self._packed = None
         self.encode_btc(mel_btc, feat_len)
         torch.cuda.synchronize(self.device)
         amax = self._calib.cpu()
         self._calib = None
-        if not bool(torch.isfinite(amax).all()) or float(amax.min()) <= 0.0:
+        if not bool(torch.isfinite(amax).all()) or float(amax[:nl].min()) <= 0.0:
             self._packed = None
             raise L.AfhipError(f"calibrate_fp8: unusable activation maxima {amax.tolist()}")
-        self._fc2_in_scale = (amax * (margin / 448.0)).to(torch.float32).contiguous()
+        self._fc2_in_scale = (amax[:nl] * (margin / 448.0)).to(torch.float32).contiguous()
+        if attention_output and float(amax[nl:].min()) > 0.0:
+            self._att_out_scale = (amax[nl:] * (margin / 448.0)).to(torch.float32).contiguous()
         self._packed = None
         return self._fc2_in_scale.clone()
 
@@ -274,6 +279,9 @@ class AFWhisperEncoder(nn.Module):
             if self._fc2_in_scale is not None:
                 keep.append(self._fc2_in_scale)                    # HOST array: the library reads it while it builds the launches
                 w.fc2_in_scale = self._fc2_in_scale.data_ptr()
+            if self._att_out_scale is not None:
+                keep.append(self._att_out_scale)                   # HOST array too
+                w.att_out_scale = self._att_out_scale.data_ptr()
             if self._calib is not None:
                 keep.append(self._calib)
                 w.calib_amax = self._calib.data_ptr()

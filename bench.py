@@ -727,10 +727,10 @@ def main():
                 "vs_bf16_output_max_abs": st_max, "vs_bf16_output_mean_abs": st_mean,
                 "dynamic_scales_only": {"encoder_ms": dyn_ms, "speedup_vs_bf16": enc_ms / dyn_ms, "vs_bf16_output_max_abs": dyn_max, "vs_bf16_output_mean_abs": dyn_mean,
                                         "what": "out-proj + fc1 on e4m3 operands, every activation quantised per row by its own pass; fc2 bf16"},
-                "what": "e4m3 x e4m3 MFMA GEMMs for out-proj, fc1 and fc2 (per-channel weight scales, f32 accumulate). out-proj / fc1 inputs: per-row scales from a quantise pass "
-                        "(LayerNorm fused for fc1); fc2 input: written as e4m3 by fc1's GELU epilogue with a per-layer static scale from AFWhisperEncoder.calibrate_fp8 "
-                        "(margin 2 x the calibration batch's max). q | k | v (LayerNorm-folded), attention and the residual stream stay bf16: with q | k | v in e4m3 the "
-                        "token-level contract of tests/test_gpu_config5.py fails"}
+                "what": "e4m3 x e4m3 MFMA GEMMs for out-proj, fc1 and fc2 (per-channel weight scales, f32 accumulate). fc1 input: per-row scales from the LayerNorm + quantise pass; "
+                        "out-proj input: written as e4m3 by the encoder attention kernel, fc2 input: by fc1's GELU epilogue -- both with per-layer static scales from "
+                        "AFWhisperEncoder.calibrate_fp8 (margin 2 x the calibration batch's max, saturating). q | k | v (LayerNorm-folded), the attention arithmetic and the "
+                        "residual stream stay bf16: with q | k | v in e4m3 the token-level contract of tests/test_gpu_config5.py fails"}
         enc.enable_fp8(False)
         del ref_out, out8, d8
         # BASELINE config 2, second run: the same 32 clips with mixed 5-30 s lengths in the self-test convention

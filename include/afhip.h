@@ -231,6 +231,11 @@ typedef struct {
      * exit.  This is how a batch of clips of different lengths runs on M = sum of lengths rows instead of B * max length
      * (afhip_encoder_forward_ragged).  NULL = [B, T] batches. */
     const int32_t* row_off;
+    /* encoder form only (bf16, head_dim 64, q_prescaled, non-causal; afhip_attention fails otherwise): out_fp8 != 0 writes `out` as OCP
+     * e4m3 BYTES (same element strides, one byte per element) = sat(value * out_scale_inv) instead of bf16 -- the statically quantised
+     * A operand of the out-projection (afhip_gemm_args.a_scale_const = 1 / out_scale_inv), without a quantisation pass. */
+    int out_fp8;
+    float out_scale_inv;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 
@@ -273,9 +278,14 @@ typedef struct {
      * layer; when present fc1's epilogue writes that activation as e4m3 directly (afhip_gemm_args.out_fp8) and fc2 runs on e4m3
      * operands with a_scale_const -- no [rows, ffn] bf16 round trip, no per-row quantisation pass.  Values come from calibration:
      * calib_amax (DEVICE array, [n_layers] f32, zeroed by the caller) makes a forward record max |GELU output| of every layer there
-     * (python: AFWhisperEncoder.calibrate_fp8).  Either may be NULL. */
+     * (python: AFWhisperEncoder.calibrate_fp8; [2 * n_layers], see att_out_scale).  Either may be NULL. */
     const float* fc2_in_scale;
     float* calib_amax;
+    /* optional, e4m3 mode only: att_out_scale (HOST array, [n_layers] f32, all > 0): static scale of the attention output per layer;
+     * when present the encoder attention kernel writes e4m3 directly (afhip_attn_args.out_fp8) and the out-projection reads it with
+     * a_scale_const.  With calib_amax set, a forward also records max |attention output| of layer l at calib_amax[n_layers + l]
+     * (calib_amax is then [2 * n_layers]). */
+    const float* att_out_scale;
 } afhip_encoder_weights;
 size_t afhip_encoder_workspace_bytes(const afhip_encoder_weights* w, int B);
 /* mel_btc [B, 2*max_pos, n_mels] (dtype of the weights); feat_len [B] int32 or NULL (no masking);

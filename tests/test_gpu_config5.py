@@ -318,7 +318,7 @@ def _teacher_forced_logits(model, kw, ids_forced, n_steps, allowed):
     return torch.stack(out_logits), picks
 
 
-@pytest.mark.parametrize("mode", ["dynamic", "static_fc2"])
+@pytest.mark.parametrize("mode", ["dynamic", "static_fc2", "static_fc2_attn"])
 def test_fp8_encoder_token_level_contract(mode):
     """What e4m3 encoder activations do to TOKEN IDS.  10 clips x 32 greedy steps through encoder ->
     adaptor -> LLM in bf16 (run A, free-running), then the same with the encoder's projections on e4m3 operands (run B,
@@ -332,17 +332,20 @@ def test_fp8_encoder_token_level_contract(mode):
     wrong side of the 90 % line -- so the shipped mode keeps q | k | v in bf16 (mask 6: out-proj + fc1 in e4m3): 296 of 320, logit
     RMSE 0.038 x std, every flip within 2.2 x RMSE.  The budget was NOT moved; the mode was.
     mode "static_fc2": additionally fc2 on e4m3 operands, its input quantised in fc1's epilogue with a per-layer static scale
-    (AFWhisperEncoder.calibrate_fp8 on a clip that is NOT one of the ten) -- the same contract, the same numbers."""
+    (AFWhisperEncoder.calibrate_fp8 on a clip that is NOT one of the ten) -- the same contract, the same numbers.
+    mode "static_fc2_attn": additionally the attention output leaves the attention kernel as e4m3 with a static scale (no quantisation
+    pass in front of the out-projection)."""
     _need_gpu()
     model, pre, lcfg, vocab, iv = _fp8_encoder_pipeline()
     io = model.multimodal_io_dict["continuous_audio"]
     enc = io.model
     enc.calibrate_fp8(None)
-    if mode == "static_fc2":
+    if mode != "dynamic":
         cal = pre.collate_fn([(("audio_to_caption", "x", "y"), {"audio": (fc.make_wav(999, 160000)[None], 16000), "text": [["user", "text", fc.make_prompt(lcfg["text_vocab"])]]})])
         enc.enable_fp8(True)
-        scales = enc.calibrate_fp8(cal["continuous_audio_feats"].to(DEV, torch.bfloat16))
+        scales = enc.calibrate_fp8(cal["continuous_audio_feats"].to(DEV, torch.bfloat16), attention_output=(mode == "static_fc2_attn"))
         assert scales is not None and bool((scales > 0).all())
+        assert (enc._att_out_scale is not None) == (mode == "static_fc2_attn")
     text_mask = oracle.ualm.masks(len(vocab), iv)["text"]
     allowed = (~text_mask[0]).to(DEV)
     n_steps, total, match, worst_ratio = 32, 0, 0, 0.0

@@ -27,9 +27,12 @@ def timed(label):
 ref, ms_bf16 = timed("bf16")
 enc.enable_fp8(True)
 dyn, ms_dyn = timed("e4m3 out + fc1, dynamic row scales (round-2 form)")
-sc = enc.calibrate_fp8(mel)
+sc = enc.calibrate_fp8(mel, attention_output=False)
 print("fc2 input scales per layer (margin 2):", [round(float(x), 4) for x in sc[:4]], "...", [round(float(x), 4) for x in sc[-2:]])
 sta, ms_sta = timed("e4m3 out + fc1 + fc2, fc2 input quantised in fc1's epilogue (static scale)")
-for name, o, ms in (("dynamic", dyn, ms_dyn), ("static fc2", sta, ms_sta)):
+enc.calibrate_fp8(mel, attention_output=True)
+print("attention output scales per layer:", [round(float(x), 4) for x in enc._att_out_scale[:4]], "...")
+sta2, ms_sta2 = timed("... + attention output written as e4m3 by the attention kernel (static scale)")
+for name, o, ms in (("dynamic", dyn, ms_dyn), ("static fc2", sta, ms_sta), ("static fc2 + attention output", sta2, ms_sta2)):
     d = (o - ref).abs()
     print(f"  {name}: {ms_bf16 / ms:.3f}x bf16 | vs bf16 output max abs {float(d.max()):.4f} mean abs {float(d.mean()):.5f} (output std {float(ref.std()):.3f})")
