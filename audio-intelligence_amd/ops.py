@@ -181,20 +181,24 @@ def transpose_cast(x: torch.Tensor, out_dtype=None):
     return y
 
 
-def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Tensor] = None, causal: bool = False, q_prescaled: bool = False):
+def attention_packed(qkv: torch.Tensor, n_heads: int, key_len: Optional[torch.Tensor] = None, causal: bool = False, q_prescaled: bool = False,
+                     out_fp8_scale: Optional[float] = None):
     """Self-attention on fused rows qkv [B,T,3*d] (q|k|v, heads contiguous inside each) -> [B,T,d].
-    q_prescaled: the q columns already carry head_dim^-0.5 * log2(e) (afhip_attn_args.q_prescaled)."""
+    q_prescaled: the q columns already carry head_dim^-0.5 * log2(e) (afhip_attn_args.q_prescaled).
+    out_fp8_scale = s: the output leaves as OCP e4m3 bytes (uint8 tensor) = sat(value / s) (afhip_attn_args.out_fp8; encoder form only)."""
     lib = L.lib()
     _chk(qkv, "attention.qkv")
     B, T, D3 = qkv.shape
     d = D3 // 3
     hd = d // n_heads
     assert qkv.is_contiguous()
-    out = torch.empty((B, T, d), dtype=qkv.dtype, device=qkv.device)
+    out = torch.empty((B, T, d), dtype=torch.uint8 if out_fp8_scale else qkv.dtype, device=qkv.device)
     sz = qkv.element_size()
     a = L.AttnArgs()
     a.q, a.k, a.v = qkv.data_ptr(), qkv.data_ptr() + d * sz, qkv.data_ptr() + 2 * d * sz
     a.out = out.data_ptr()
+    if out_fp8_scale:
+        a.out_fp8, a.out_scale_inv = 1, 1.0 / float(out_fp8_scale)
     a.key_len = key_len.data_ptr() if key_len is not None else None
     a.B, a.Tq, a.Tk, a.n_q, a.n_kv, a.hd = B, T, T, n_heads, n_heads, hd
     a.ld_q = a.ld_kv = D3

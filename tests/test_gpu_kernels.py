@@ -847,3 +847,34 @@ def test_attention_encoder_two_forms_bit_identical(T, lens, monkeypatch):
         rows = torch.cat([qkv[i, :n] for i, n in enumerate(lens)], 0).contiguous()
         a, b = both(lambda: ops.attention_ragged(rows, H, torch.tensor(lens, dtype=torch.int32), max(lens), q_prescaled=True))
         assert torch.equal(a, b)
+
+
+def test_attention_encoder_e4m3_output():
+    """afhip_attn_args.out_fp8 (encoder form): the output written as OCP e4m3 bytes = sat(value / s).  Dequantised it is within one
+    e4m3 step of the bf16 output of the same call (2^-3 relative, 2^-9 s at the small end); a scale too small on purpose saturates at
+    448 s instead of producing NaN; full clips and ragged key lengths; forms that are not the encoder form refuse the flag."""
+    from audio_intelligence_amd import ops, _lib as L
+    B, T, H = 3, 700, 20
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * 0.7)
+    qkv[:, :, : H * 64] *= 0.125 * math.log2(math.e) * 3.0
+    qkv = qkv.to(torch.bfloat16).to(_dev())
+    kl = torch.tensor([700, 333, 65], dtype=torch.int32, device=_dev())
+    for key_len in (None, kl):
+        ref = ops.attention_packed(qkv, H, key_len=key_len, q_prescaled=True).float()
+        amax = float(ref.abs().max())
+        for s in (2.0 * amax / 448.0, 0.25 * amax / 448.0):
+            q8 = ops.attention_packed(qkv, H, key_len=key_len, q_prescaled=True, out_fp8_scale=s)
+            assert q8.dtype == torch.uint8 and q8.shape == ref.shape
+            deq = q8.view(torch.float8_e4m3fn).float() * s
+            if key_len is not None:
+                for b in range(B):
+                    deq[b, int(kl[b]):] = 0
+                    ref[b, int(kl[b]):] = 0
+            assert bool(torch.isfinite(deq).all())
+            want = ref.clamp(-448.0 * s, 448.0 * s)
+            err = (deq - want).abs()
+            tol = want.abs() * (2.0 ** -3) + s * (2.0 ** -9) + 1e-2 * want.abs()
+            assert bool((err <= tol).all()), (s, float((err - tol).max()))
+    with pytest.raises(L.AfhipError):
+        ops.attention_packed(qkv, H, q_prescaled=False, out_fp8_scale=0.01)      # the plain kernel has no e4m3 epilogue
