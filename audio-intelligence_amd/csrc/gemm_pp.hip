@@ -378,10 +378,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
 
-    // a wave group whose 128 rows of the output tile lie entirely past M (the lower half of the last M tile: M = 48 000 = 187.5 tiles) keeps
-    // the DMA / barrier cadence but issues no MFMAs: its partner then has the matrix pipe to itself, and the 15 such tiles of the q | k | v
-    // GEMM -- a round of their own, 2820 = 11 x 256 + 4 -- cost about half a tile
-    bool live = true;
     // one K tile in stage S
     auto ktile = [&](auto s_tag) {
         constexpr int S = decltype(s_tag)::value;
@@ -426,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 (t+1), A1(t+1) in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
-            if (live) mfma_half(I0{});
+            mfma_half(I0{});
             PP_BARRIER();
             // phase 1
             read_a(st + PP_OFF_A1);
@@ -436,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             PP_WAIT_VM8();                            // A0 B0 B1 (t+1) landed; A1(t+1), A0 B0 B1 (t+2) in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
-            if (live) mfma_half(I1{});
+            mfma_half(I1{});
             PP_BARRIER();
         } else {
 #if PP_SCHED == 1
@@ -452,26 +448,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         x0();
         PP_WAIT_VM10();                           // B1(t) landed; A1(t) A0 B0 B1 (t+1) A1(t+1) in flight
         PP_BARRIER();
-        if (live) mfma_quad(I0{}, I0{}, fb0, nodma);
+        mfma_quad(I0{}, I0{}, fb0, nodma);
         PP_BARRIER();
         // phase 1: reads B1 (t)
         read_b(st + PP_OFF_B1, fb1);
         PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 A1 (t+1) in flight
         PP_BARRIER();
-        if (live) mfma_quad(I0{}, I1{}, fb1, nodma);
+        mfma_quad(I0{}, I1{}, fb1, nodma);
         PP_BARRIER();
         // phase 2: reads A1 (t); refills A0 and B0 of this stage (read in phase 0)
         read_a(st + PP_OFF_A1);
         dma2();
         dma3();
         PP_BARRIER();
-        if (live) mfma_quad(I1{}, I1{}, fb1, nodma);
+        mfma_quad(I1{}, I1{}, fb1, nodma);
         PP_BARRIER();
         // phase 3: refills B1 of this stage (read in phase 1)
         x3();
         PP_WAIT_VM10();                           // A0 B0 (t+1) landed; B1 A1 (t+1) A0 B0 B1 (t+2) in flight
         PP_BARRIER();
-        if (live) mfma_quad(I1{}, I0{}, fb0, nodma);
+        mfma_quad(I1{}, I0{}, fb0, nodma);
         PP_BARRIER();
 #else
         // phase 0
@@ -493,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
-        if (live) mfma_quad(I0{}, I0{}, fb0, dma0);
+        mfma_quad(I0{}, I0{}, fb0, dma0);
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -509,7 +505,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
-        if (live) mfma_quad(I0{}, I1{}, fb1, dma1);
+        mfma_quad(I0{}, I1{}, fb1, dma1);
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -525,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
-        if (live) mfma_quad(I1{}, I1{}, fb1, dma2);
+        mfma_quad(I1{}, I1{}, fb1, dma2);
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -541,7 +537,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
-        if (live) mfma_quad(I1{}, I0{}, fb0, dma3);
+        mfma_quad(I1{}, I0{}, fb0, dma3);
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -552,11 +548,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     };
 
     for (int it = 0; it < n_my; ++it) {
-        {
-            int m0_, n0_;
-            pp_tile_coords(p, (int)blockIdx.x + it * (int)gridDim.x, m0_, n0_);
-            live = m0_ + grp * 128 < p.M;
-        }
         for (int k2 = 0; k2 < nk2; ++k2) {
 #ifdef AFHIP_PP_STAMPS
             st_on = st_wave && it == 1 && k2 == 4;
