@@ -211,3 +211,49 @@ def test_tiny_pipeline_fp8_prefill_and_decode_budget():
     rmse = (se / n) ** 0.5
     print(f"fp8 prefill + W8A16 decode, tiny UALM: logit RMSE {rmse:.4f}, teacher-forced match {match}/320")
     assert rmse <= 0.06 and match >= 272
+
+
+def test_absmax_bf16_and_calibration_scales():
+    """afhip_absmax_bf16 (the calibration helper behind afhip_encoder_weights.fc2_in_scale / att_out_scale): max |x| of a bf16 buffer merged
+    into a zeroed float by an atomic max on the bit pattern -- exact, order-independent, accumulating over calls; bad sizes are refused.
+    Then AFWhisperEncoder.calibrate_fp8 on a 2-layer full-width encoder: the recorded maxima are those of the tensors themselves
+    (hidden_layer output cannot show them, so the check is the scale arithmetic: margin x amax / 448, finite, positive, dropped by None)."""
+    _need_gpu()
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(3, 4096 * 8, generator=g) * 3.0).to(torch.bfloat16)
+    x[1, 12345] = -77.5
+    xd = x.to(DEV)
+    out = torch.zeros(2, dtype=torch.float32, device=DEV)
+    L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xd[0].data_ptr()), C.c_longlong(xd[0].numel()), C.c_void_p(out.data_ptr()), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(out[0]) == float(x[0].float().abs().max()) and float(out[1]) == 0.0
+    L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xd.data_ptr()), C.c_longlong(xd.numel()), C.c_void_p(out.data_ptr()), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(out[0]) == 77.5
+    with pytest.raises(L.AfhipError):
+        L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xd.data_ptr()), C.c_longlong(12), C.c_void_p(out.data_ptr()), L.stream_ptr()))
+    from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
+    from audio_intelligence_amd.utils import synthetic as syn
+    cfg = dict(oracle.afwhisper.default_config())
+    cfg["encoder_layers"] = 2
+    enc = AFWhisperEncoder(AFWhisperEncoderConfig.from_dict(cfg))
+    enc.load_state_dict(syn.synth_state_dict(syn.encoder_param_shapes(cfg), 21), strict=True)
+    enc = enc.to(DEV, torch.bfloat16)
+    mel = torch.from_numpy(H.mel_of(2000, 480000))[None].transpose(1, 2).contiguous().to(DEV, torch.bfloat16)
+    with pytest.raises(L.AfhipError):
+        enc.calibrate_fp8(mel)                                     # fp8 mode not enabled
+    enc.enable_fp8(True)
+    base = enc.encode_btc(mel)
+    s1 = enc.calibrate_fp8(mel, margin=2.0)
+    s2 = enc.calibrate_fp8(mel, margin=4.0)
+    assert s1.shape == (2,) and bool((s1 > 0).all()) and bool(torch.isfinite(s1).all())
+    assert torch.allclose(s2, 2.0 * s1)                            # same maxima, twice the margin
+    assert enc._att_out_scale is not None and bool((enc._att_out_scale > 0).all())
+    stat = enc.encode_btc(mel)
+    assert not torch.equal(stat, base)                             # the static path is really taken
+    rel = float((stat.float() - base.float()).pow(2).mean().sqrt() / base.float().pow(2).mean().sqrt())
+    assert rel < 0.1, rel                                          # and stays an e4m3-sized perturbation of the dynamic mode
+    assert enc.calibrate_fp8(None) is None and enc._fc2_in_scale is None and enc._att_out_scale is None
+    assert torch.equal(enc.encode_btc(mel), base)                  # scales dropped: back to the dynamic mode, bit for bit
