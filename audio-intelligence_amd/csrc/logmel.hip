@@ -62,35 +62,58 @@ constexpr int KCMAX = 12;
 // LAYOUT 1: out [B][3000][128] (time-major, what the encoder consumes): a frame's 128 mels are one coalesced row.
 // LAYOUT 0: out [B][128][3000] (the reference's layout): the tile goes through the LDS tile `tr` [NFR][129] and leaves as runs of
 //           NFR consecutive frames per mel.
-template <int NFR, int PITCH, typename TO, int LAYOUT>
-__device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
-                                          TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int tid) {
-    const int m = tid & 127;
+// one 64-mel half (mels mbase .. mbase + 63, one per lane) over the frames w, w + 4, ... of the tile (w = wave), band padded to PAD
+// elements.  Fully unrolled, no early exit: frames past the clip end still have their row in the tile and are simply not stored, so all
+// power reads are independent and hipcc may issue them as far ahead as it has registers.  The band is read CONTIGUOUSLY (k0 .. k0 + PAD - 1,
+// pairs merge into ds_read2_b32); past the band the weight is 0 and the value read -- the next bins, or for the last row whatever finite
+// floats follow the tile -- adds exactly +0, so the sum keeps the reference's left-to-right order and its bits.
+template <int NFR, int PITCH, typename TO, int LAYOUT, int PAD>
+__device__ __forceinline__ float mel_tail_half(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
+                                               TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int m, int w) {
     const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
-    float wk[KCMAX];
+    float wk[PAD];
 #pragma unroll
-    for (int k = 0; k < KCMAX; ++k) wk[k] = k < kc ? cw[wo + k] : 0.f;
+    for (int k = 0; k < PAD; ++k) wk[k] = k < kc ? cw[wo + k] : 0.f;
     float mx = -INFINITY;
-#pragma unroll 4
-    for (int f = tid >> 7; f < NFR; f += 2) {
-        const int t = t0 + f;
-        if (t >= NFRAMES) break;
-        float pv[KCMAX];
 #pragma unroll
-        for (int k = 0; k < KCMAX; ++k) {
-            const int kk = k < kc ? k0 + k : k0;          // stay inside this frame's row
-            pv[k] = pw[f * PITCH + kk];
-        }
+    for (int fi = 0; fi < NFR / 4; ++fi) {
+        const int f = w + 4 * fi;
+        const int t = t0 + f;
+        float pv[PAD];
+#pragma unroll
+        for (int k = 0; k < PAD; ++k) pv[k] = pw[f * PITCH + k0 + k];
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < KCMAX; ++k) acc = fmaf(wk[k], pv[k], acc);   // same left-to-right order as the reference's band sum
+        for (int k = 0; k < PAD; ++k) acc = fmaf(wk[k], pv[k], acc);
         // log10 = log2 * log10(2) on v_log_f32 (1 ulp; the argument is >= 1e-10, far from the denormal range)
         const float v = __builtin_amdgcn_logf(fmaxf(acc, 1e-10f)) * 0.30102999566398120f;
         const float y = (v + 4.0f) / 4.0f;                 // the per-clip floor is applied in place by logmel_floor_kernel
-        if constexpr (LAYOUT == 1) out[((long long)b * NFRAMES + t) * NMEL + m] = from_f32<TO>(y);
-        else tr[f * (NMEL + 1) + m] = y;
-        mx = fmaxf(mx, v);
+        if (t < NFRAMES) {
+            if constexpr (LAYOUT == 1) out[((long long)b * NFRAMES + t) * NMEL + m] = from_f32<TO>(y);
+            else tr[f * (NMEL + 1) + m] = y;
+            mx = fmaxf(mx, v);
+        }
     }
+    return mx;
+}
+
+template <int NFR, int PITCH, typename TO, int LAYOUT>
+__device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
+                                          TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int tid) {
+    // Round 3 (stamps: this tail was 37 % of a tile's time).  Whisper's 128 bands hold 1-2 bins below mel 64 and up to 9 above (394 in
+    // all), so "one mel per thread, padded to 12" did 3.9x the band work and left the low-mel waves idle behind the high-mel ones.  Now
+    // every wave takes a quarter of the frames and walks them twice: the 64 HIGH mels padded to the widest band among them, then the 64
+    // LOW mels padded to theirs (wave-uniform, taken from the band table; 9 + 2 = 11 units per frame instead of 2 x 12).
+    const int lane = tid & 63, w = tid >> 6;
+    int ka = cband[3 * lane + 1], kb = cband[3 * (64 + lane) + 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ka = max(ka, __shfl_xor(ka, o, 64)); kb = max(kb, __shfl_xor(kb, o, 64)); }
+    float mx;
+    if (kb <= 9) mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, 9>(pw, cw, cband, out, tr, b, t0, 64 + lane, w);
+    else mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, 64 + lane, w);
+    if (ka <= 2) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 2>(pw, cw, cband, out, tr, b, t0, lane, w));
+    else if (ka <= 4) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 4>(pw, cw, cband, out, tr, b, t0, lane, w));
+    else mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, lane, w));
     if constexpr (LAYOUT == 0) {
         __syncthreads();
         for (int idx = tid; idx < NFR * NMEL; idx += 256) {
