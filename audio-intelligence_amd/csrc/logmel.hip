@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
 //     Z[q + 25 bitrev3(t)], q = 0..24;
 //   * the real-input spectrum is unpacked from Z[k] and conj Z[200-k] (lane ^ 7, register 25 - q), power -> LDS,
 //     then the same banded mel / log10 / running-max tail as the DFT form.
+#ifndef LM_WG_PER_CU
+#define LM_WG_PER_CU 2   /* workgroups per CU the FFT form is compiled for (register budget 512 / (2 x this) per lane) */
+#endif
 constexpr int FFT_FT = 32;                 // frames per workgroup
 constexpr int FFT_PITCH = 176;             // LDS floats per hop row: 176 f mod 64 = 0, 48, 32, 16 -> the 4 frames of a 32-lane group hit disjoint banks
 constexpr int FFT_ROWS = FFT_FT + 2;       // hops touched: 31 + ceil(400 / 160)
@@ -336,7 +339,7 @@ __device__ __forceinline__ void dft5(float& r0, float& i0, float& r1, float& i1,
 }
 
 template <typename TO, int LAYOUT>
-__global__ __launch_bounds__(256, 2) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
+__global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
                                                         const float* __restrict__ tab, TO* __restrict__ out,
                                                         int* __restrict__ clipmax, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
