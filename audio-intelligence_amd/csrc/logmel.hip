@@ -42,7 +42,7 @@ struct Tables {
     static constexpr size_t COFF = BAND + 2 * NMEL;                   // [NMEL] int32 offset of the mel's weights in CW
     static constexpr size_t CW = COFF + NMEL;                         // [CWMAX] non-zero weights, mel-major
     static constexpr size_t CWMAX = 512;
-    static constexpr size_t TW200 = CW + CWMAX;                       // [200][2] e^{-2 pi i j / 200} (FFT path)
+    static constexpr size_t TW200 = CW + CWMAX;                       // [25][8][2] e^{-2 pi i t q / 200} (FFT path)
     static constexpr size_t WINF = TW200 + 400;                       // [400] periodic Hann window (FFT path)
     static constexpr size_t TOTAL = WINF + 400;
 };
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
 constexpr int FFT_FT = 32;                 // frames per workgroup
 constexpr int FFT_PITCH = 176;             // LDS floats per hop row: 176 f mod 64 = 0, 48, 32, 16 -> the 4 frames of a 32-lane group hit disjoint banks
 constexpr int FFT_ROWS = FFT_FT + 2;       // hops touched: 31 + ceil(400 / 160)
-constexpr int FFT_PROW = 203;              // LDS pitch of the power tile
+constexpr int FFT_PROW = 216;              // LDS pitch of the power tile: 216 f + 25 k1 mod 32 is a bijection of (4 frames x 8 lanes) onto the 32 banks of a ds_write_b32 group (203 gave 2-way conflicts)
 constexpr int FFT_MAIN = (FFT_ROWS * FFT_PITCH > FFT_FT * FFT_PROW) ? FFT_ROWS * FFT_PITCH : FFT_FT * FFT_PROW;
 
 constexpr float W25R[17] = {1.000000000e+00f, 9.685831611e-01f, 8.763066800e-01f, 7.289686274e-01f, 5.358267950e-01f, 3.090169944e-01f, 6.279051953e-02f, -1.873813146e-01f, -4.257792916e-01f, -6.374239897e-01f, -8.090169944e-01f, -9.297764859e-01f, -9.921147013e-01f, -9.921147013e-01f, -9.297764859e-01f, -8.090169944e-01f, -6.374239897e-01f};
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
 #pragma unroll
         for (int kb = 0; kb < 5; ++kb) {
             const int q = ka + 5 * kb;
-            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw_t + 2 * (t * q));
+            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw_t + 2 * (q * 8 + t));
             const float ar = zr[5 * ka + kb], ai = zi[5 * ka + kb];
             yr[q] = ar * tv[0] - ai * tv[1];
             yi[q] = ar * tv[1] + ai * tv[0];
@@ -589,10 +589,15 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
             if (n < 200) t[Tables::SIN + (size_t)k * KPAD + i] = (float)(-sin(two_pi * (double)kn / NFFT));
         }
     for (int i = 0; i < 200; ++i) t[Tables::WIN + i] = (float)(0.5 - 0.5 * cos(two_pi * (double)(i + 1) / NFFT));
-    for (int j = 0; j < 200; ++j) {
-        t[Tables::TW200 + 2 * j] = (float)cos(two_pi * (double)j / 200.0);
-        t[Tables::TW200 + 2 * j + 1] = (float)(-sin(two_pi * (double)j / 200.0));
-    }
+    // inter-stage twiddles of the FFT form, laid out [q = 0..24][t = 0..7] = e^{-2 pi i t q / 200}: the 8 lanes of a frame read 8 consecutive
+    // 8-byte entries (16 banks), the 4 frames of a 32-lane group the same ones -- conflict-free for every q.  (The [j = t q] table this
+    // replaces put lanes t on banks 2 t q mod 64: 2- to 4-way conflicts whenever q is a multiple of 4.)
+    for (int q = 0; q < 25; ++q)
+        for (int tt = 0; tt < 8; ++tt) {
+            const int j = tt * q;
+            t[Tables::TW200 + 2 * (q * 8 + tt)] = (float)cos(two_pi * (double)j / 200.0);
+            t[Tables::TW200 + 2 * (q * 8 + tt) + 1] = (float)(-sin(two_pi * (double)j / 200.0));
+        }
     for (int n = 0; n < NFFT; ++n) t[Tables::WINF + n] = (float)(0.5 - 0.5 * cos(two_pi * (double)n / NFFT));
     memcpy(t + Tables::FILT, filters_host, sizeof(float) * NBIN * NMEL);
     int* band = reinterpret_cast<int*>(t + Tables::BAND);
