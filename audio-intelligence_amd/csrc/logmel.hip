@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
 //   * the real-input spectrum is unpacked from Z[k] and conj Z[200-k] (lane ^ 7, register 25 - q), power -> LDS,
 //     then the same banded mel / log10 / running-max tail as the DFT form.
 #ifndef LM_WG_PER_CU
-#define LM_WG_PER_CU 2   /* workgroups per CU the FFT form is compiled for (register budget 512 / (2 x this) per lane) */
+#define LM_WG_PER_CU 3   /* workgroups per CU the FFT form is compiled for (register budget 512 / this per lane: 2 waves per SIMD -> 256, 3 -> 168).
+                            3: no hoisted window, no register prefetch of the next tile's samples, 162 VGPRs: 70.4-71.8 us per 32 clips against
+                            74.2 with 2 (same box); 4 would spill 43 registers */
 #endif
 constexpr int FFT_FT = 32;                 // frames per workgroup
 constexpr int FFT_PITCH = 176;             // LDS floats per hop row: 176 f mod 64 = 0, 48, 32, 16 -> the 4 frames of a 32-lane group hit disjoint banks
@@ -444,12 +446,17 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
     const int t0 = tile * FFT_FT;
     const int next = tile + (int)gridDim.x;
     const bool next_interior = next < NTILE && tile_interior(next);
+#if LM_WG_PER_CU < 3
     if (next_interior) load_tile(next);                      // in flight during this tile's arithmetic
+#endif
     // the window, twiddle and W400 values are loop-invariant per lane: the 50 window values are left to be hoisted into
     // registers for the life of the workgroup (2 waves per SIMD have the room), the twiddle table base and the W400 lane factor
     // are hidden behind opaque moves so those 100 values are NOT hoisted too (256 VGPRs + scratch otherwise)
     const float* wn_t = wn; const float* tw_t = tw;
     asm volatile("" : "+v"(tw_t));
+#if LM_WG_PER_CU >= 3
+    asm volatile("" : "+v"(wn_t));                              // three workgroups per CU: no room for the hoisted window either
+#endif
     float lr_t = lr, li_t = li;                                 // likewise the 25 per-lane W400 products of the unpack
     asm volatile("" : "+v"(lr_t), "+v"(li_t));
     // ---- load + window: z[m] = (x[16m + 2t], x[16m + 2t + 1]) . w ----
@@ -534,6 +541,9 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
     LM_STAMP(7);
     if (next < NTILE) {
         __syncthreads();                                     // the power tile has been consumed: LDS takes the next samples
+#if LM_WG_PER_CU >= 3
+        if (next_interior) load_tile(next);                  // no register prefetch: the other workgroups of the CU cover this latency
+#endif
         if (next_interior) store_tile(); else stage_edge_tile(next);
         __syncthreads();
     }
@@ -642,8 +652,8 @@ void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* o
         const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FFT_FT * (NMEL + 1) : 0));
         const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
         unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
-        // persistent over frame tiles: 2 workgroups per CU in one generation (512 on 256 CUs; 2 waves per SIMD by registers), each walking ceil(94 / gx) tiles
-        int gx = cdiv(512, B);
+        // persistent over frame tiles: LM_WG_PER_CU workgroups per CU in one generation, each walking ceil(94 / gx) tiles
+        int gx = cdiv(256 * LM_WG_PER_CU, B);
         gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);
         hipLaunchKernelGGL((logmel_pass1_fft<TO, LAYOUT>), dim3(gx, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
                            tables, out, clipmax, dbg);
