@@ -290,6 +290,9 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
     EncBlk cur, nxt;
     int v = next_valid((int)blockIdx.x, cur);
     if (v < 0) return;                                           // workgroup-uniform, before any barrier
+#ifdef AFHIP_ENC_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();   // this workgroup's own duration (the counters of different XCDs are not aligned)
+#endif
     dma_q(cur);
     prefetch_tiles(cur);
     {   // V fragment sets = 0 once: the first slot of every block multiplies "V(-1)" (whatever the sets hold: finite) by P_b(-1) = 0
@@ -595,6 +598,11 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef AFHIP_ENC_STAMPS
+    if (p.dbg && wave == 0) {      // every workgroup's duration at [128 + blockIdx.x] (the load-balance question: tools/attn_enc_stamps.py)
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime() - t_start;
+        const int off_ = (128 + (int)blockIdx.x) * 8;
+        asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(t_), "s"(p.dbg), "s"(off_) : "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
