@@ -14,7 +14,7 @@
 //              re-evaluates the activation for its whole K range, so it only pays for very narrow outputs);
 // and SwiGLU can instead be the EPILOGUE of the gate/up GEMM (`swiglu_out`): a NT = 4 workgroup owns exactly one 64-row
 // gate/up block pair, so the K-slice combine emits silu(gate) * up straight into the [M, N/2] activation (modeling_qwen2.py:46-48).
-#include "common.h"
+#include "skinny.h"
 #include <stdlib.h>
 
 #ifndef SKINNY_DEPTH
@@ -29,23 +29,7 @@
 
 namespace {
 
-enum { A_PLAIN = 0, A_RMSNORM = 1, A_SWIGLU = 2 };
-
-struct SkinnyP {
-    const char* A;
-    const char* W;
-    const char* bias;
-    const char* res;
-    const char* norm_w;
-    char* C;
-    int M, N, K;
-    long long lda, ldw, ldc, ldres;
-    int out_f32;
-    float norm_eps;
-    int swiglu_out;
-    int a_rows;      // ALDS: rows of the activation image kept in LDS (8 or 16, >= M)
-    int tile_rows;   // weight rows per 16-wide MFMA tile that carry work (<= 16): narrow outputs are cut into ceil(N / CUs)-row shares so every CU streams the same bytes
-};
+enum { A_PLAIN = SKINNY_A_PLAIN, A_RMSNORM = SKINNY_A_RMSNORM, A_SWIGLU = SKINNY_A_SWIGLU };
 
 template <typename T> struct Step;
 template <> struct Step<bf16> { static constexpr int K = 64; };
@@ -578,6 +562,17 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
         nt_narrow = rpw <= 16 ? 1 : 2;
         p.tile_rows = rpw <= 16 ? rpw : (rpw <= 32 ? cdiv(rpw, 2) : 16);
         if (mt > 2 && nt_narrow == 2) { nt_narrow = 1; p.tile_rows = 16; }      // LDS of the K-slice combine: NT * MT <= 4 tiles
+    }
+    p.n_tiles = 1; p.am_iv = nullptr; p.am_n_iv = 0; p.am_val = nullptr; p.am_idx = nullptr;
+    if (a->dtype == AFHIP_BF16 && mt == 1) {
+        // the 7B decode step's form: one persistent workgroup per CU, the A operand through LDS only (gemm_stream.hip).
+        // AFHIP_SKINNY_STREAM=0 keeps the round-3 kernels (A/B switch, read per call so one process can compare the forms bit for bit)
+        const char* se = getenv("AFHIP_SKINNY_STREAM");
+        if (!(se && se[0] == '0')) {
+            SkinnyP ps = p;
+            ps.n_tiles = sw_out ? 2 : (wide ? (p.a_rows == 8 ? 4 : 2) : nt_narrow);
+            if (afhip_gemm_stream_bf16(ps, amode, s)) { AFHIP_LAUNCH_CHECK(); return 0; }
+        }
     }
     if (a->dtype == AFHIP_BF16 && sw_out && mt == 1 && amode != A_SWIGLU && a->K % 512 == 0) {
         // decode gate/up: the persistent pair form (one continuous weight stream per CU); AFHIP_SKINNY_PERSIST=0 keeps the plain form

@@ -3,6 +3,7 @@
 // (modeling_qwen2.py:258-299), with a preallocated [layer][B][kv_head][cap][hd] KV cache instead of DynamicCache,
 // and the greedy pick + stop bookkeeping of lm/parallel.py:494-513,599-601 kept on the device.
 #include "common.h"
+#include "decode_chain.h"
 
 namespace {
 
@@ -212,6 +213,48 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
     return tot;
 }
 
+// attention of layer l over the KV cache: causal GQA prefill, or (decode_attn) one new token per sequence -- the `rep` query heads that
+// share a kv head are the query rows of one workgroup, RoPE + the cache append ride inside the launch, the context is split into
+// key ranges over workgroups and merged (flash-decoding)
+static int layer_attention(const afhip_llm_weights* w, const LlmWs& ws, int l, int B, int T, int pos0, afhip_kv_cache* cache, const int32_t* seq_pos,
+                           bool decode_attn, hipStream_t s) {
+    const int dt = w->dtype, nq = w->n_q, nkv = w->n_kv, hd = w->hd;
+    const size_t sz = dtype_size(dt);
+    const int qw = (nq + 2 * nkv) * hd, rep = nq / nkv;
+    const size_t layer_kv = (size_t)cache->B * nkv * cache->cap * hd * sz;
+    char* kc = (char*)cache->k + (size_t)l * layer_kv;
+    char* vc = (char*)cache->v + (size_t)l * layer_kv;
+    afhip_attn_args a = {};
+    a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
+    a.hd = hd; a.ld_kv = hd;
+    a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.kv_head_stride = (long long)cache->cap * hd;
+    a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt; a.q_prescaled = 0;
+    a.B = B; a.Tk = pos0 + T;
+    if (decode_attn) {
+        // decode: the `rep` query heads that share a kv head are the query rows of one workgroup, so each K/V byte is
+        // streamed once per group; the context is split into DECODE_KEY_SPLIT-key ranges over workgroups and merged (flash-decoding)
+        a.Tq = rep; a.n_q = nkv; a.n_kv = nkv;
+        a.ld_q = hd; a.q_head_stride = (long long)rep * hd; a.q_batch_stride = qw;
+        a.ld_o = hd; a.o_head_stride = (long long)rep * hd; a.o_batch_stride = (long long)nq * hd;
+        a.causal = 0; a.q_pos0 = 0;
+        a.key_split = decode_key_split(); a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
+        a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
+        a.seq_pos = seq_pos;
+        a.rope_cos = seq_pos ? w->rope_cos : w->rope_cos + (size_t)pos0 * (hd / 2);
+        a.rope_sin = seq_pos ? w->rope_sin : w->rope_sin + (size_t)pos0 * (hd / 2);
+        // the in-launch merge (a.split_ticket = ws.ticket + l * B * nkv) is correct and bit-identical but SLOWER here: 4.10 vs 3.76 ms
+        // per 7B step -- 224 workgroups each paying an agent-scope release (L2 write-back) cost more than one 5-us combine launch
+        a.split_ticket = DECODE_IN_LAUNCH_MERGE ? ws.ticket + (size_t)l * B * nkv : nullptr;
+    } else {
+        a.Tq = T; a.n_q = nq; a.n_kv = nkv;
+        a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;
+        a.ld_o = nq * hd; a.o_head_stride = 0; a.o_batch_stride = (long long)T * nq * hd;
+        a.causal = 1; a.q_pos0 = pos0;
+        a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
+    }
+    return afhip_attention(&a, s);
+}
+
 static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, int T, int pos0, afhip_kv_cache* cache,
                             void* hidden_out, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seq_pos) {
     AFHIP_CHECK(w && x && cache && hidden_out && workspace, "afhip_llm_forward: null pointer");
@@ -266,35 +309,7 @@ static int llm_forward_impl(const afhip_llm_weights* w, const void* x, int B, in
         const bool decode_attn = T == 1 && rep <= 32;
         // decode: RoPE and the cache append ride inside the attention launch (afhip_attn_args.new_k); prefill: their own pass
         if (!decode_attn && (rc = afhip_rope_kv(ws.qkv, qw, w->rope_cos, w->rope_sin, pos0, kc, vc, B, T, nq, nkv, hd, cache->cap, w->rope_max_pos, dt, s))) return rc;
-        afhip_attn_args a = {};
-        a.q = ws.qkv; a.k = kc; a.v = vc; a.out = ws.att; a.key_len = nullptr;
-        a.hd = hd; a.ld_kv = hd;
-        a.kv_batch_stride = (long long)nkv * cache->cap * hd; a.kv_head_stride = (long long)cache->cap * hd;
-        a.scale = 1.0f / sqrtf((float)hd); a.dtype = dt; a.q_prescaled = 0;
-        a.B = B; a.Tk = pos0 + T;
-        if (decode_attn) {
-            // decode: the `rep` query heads that share a kv head are the query rows of one workgroup, so each K/V byte is
-            // streamed once per group; the context is split into DECODE_KEY_SPLIT-key ranges over workgroups and merged (flash-decoding)
-            a.Tq = rep; a.n_q = nkv; a.n_kv = nkv;
-            a.ld_q = hd; a.q_head_stride = (long long)rep * hd; a.q_batch_stride = qw;
-            a.ld_o = hd; a.o_head_stride = (long long)rep * hd; a.o_batch_stride = (long long)nq * hd;
-            a.causal = 0; a.q_pos0 = 0;
-            a.key_split = decode_key_split(); a.partial_ws = ws.part; a.partial_ws_bytes = ws.part_bytes;
-            a.new_k = ws.qkv + (size_t)nq * hd * sz; a.new_v = ws.qkv + (size_t)(nq + nkv) * hd * sz; a.new_kv_batch_stride = qw;
-            a.seq_pos = seq_pos;
-            a.rope_cos = seq_pos ? w->rope_cos : w->rope_cos + (size_t)pos0 * (hd / 2);
-            a.rope_sin = seq_pos ? w->rope_sin : w->rope_sin + (size_t)pos0 * (hd / 2);
-            // the in-launch merge (a.split_ticket = ws.ticket + l * B * nkv) is correct and bit-identical but SLOWER here: 4.10 vs 3.76 ms
-            // per 7B step -- 224 workgroups each paying an agent-scope release (L2 write-back) cost more than one 5-us combine launch
-            a.split_ticket = DECODE_IN_LAUNCH_MERGE ? ws.ticket + (size_t)l * B * nkv : nullptr;
-        } else {
-            a.Tq = T; a.n_q = nq; a.n_kv = nkv;
-            a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;
-            a.ld_o = nq * hd; a.o_head_stride = 0; a.o_batch_stride = (long long)T * nq * hd;
-            a.causal = 1; a.q_pos0 = pos0;
-            a.key_split = 0; a.partial_ws = nullptr; a.partial_ws_bytes = 0;
-        }
-        if ((rc = afhip_attention(&a, s))) return rc;
+        if ((rc = layer_attention(w, ws, l, B, T, pos0, cache, seq_pos, decode_attn, s))) return rc;
         if (p8) {
             if ((rc = afhip_quant_rows(ws.att, nq * hd, nullptr, nullptr, 0.f, 0, q8, sc8, rows, nq * hd, s))) return rc;
             if ((rc = gemm8(q8, sc8, w->o_w8[l], w->o_s[l], nullptr, ws.x, ws.x, rows, H, nq * hd, H, H, AFHIP_ACT_NONE, s))) return rc;
@@ -409,10 +424,33 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     char* hid = base + off; off += align256((size_t)B * H * sz);
     char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);
     int rc;
+    AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
+    if (w->qkv_w8 == nullptr && w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B) &&
+        (size_t)B * w->vocab * sizeof(float) >= afhip_decode_chain_scratch_bytes(B)) {
+        // bf16 weights, B <= 16: the dependent GEMMs of the step run as chains inside one launch per layer (decode_chain.hip); the
+        // attention launches stay between them.  The f32 logits region of the workspace is not used here: it holds the barrier words
+        // and the argmax partials
+        AFHIP_CHECK(pos >= 0 && pos + 1 <= cache->cap && pos + 1 <= w->rope_max_pos && cache->B >= B && cache->k && cache->v,
+                    "afhip_llm_decode_step: position %d exceeds the KV capacity %d / rope table %d, or cache batch %d < %d", pos, cache->cap, w->rope_max_pos, cache->B, B);
+        AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_decode_step: head_dim %d unsupported", w->hd);
+        const LlmWs ws = carve(w, B, base, cache->cap);
+        if (hipMemsetAsync(logits, 0, 2048, s) != hipSuccess) { afhip_set_error("decode step: barrier memset failed"); return AFHIP_ERR_LAUNCH; }
+        afhip_chain_step c = {};
+        c.w = w; c.B = B; c.x = ws.x; c.qkv = ws.qkv; c.att = ws.att; c.act = ws.act; c.scratch = logits; c.st = st; c.step = step;
+        int rounds = 0;
+        c.layer = -1; c.bar0 = 0;
+        if ((rc = afhip_decode_chain_launch(c, s, &rounds))) return rc;
+        for (int l = 0; l < w->n_layers; ++l) {
+            c.bar0 += rounds;
+            if ((rc = layer_attention(w, ws, l, B, 1, pos, cache, st->seq_pos, true, s))) return rc;
+            c.layer = l;
+            if ((rc = afhip_decode_chain_launch(c, s, &rounds))) return rc;
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);
     AFHIP_LAUNCH_CHECK();
     if ((rc = afhip_embed_sum(ids, w->embed, emb, B, S, H, w->vocab, dt, s))) return rc;
-    AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
     if ((rc = llm_forward_impl(w, emb, B, 1, pos, cache, hid, workspace, fwd_bytes, s, st->seq_pos))) return rc;
     if ((rc = afhip_lm_head(w, hid, B, 1, logits, hs, align256((size_t)B * S * H * sz), s))) return rc;
     if ((rc = afhip_masked_argmax(logits, B, w->vocab, st->allowed, st->n_iv, tok, dt, am, afhip_masked_argmax_workspace_bytes(B), s))) return rc;

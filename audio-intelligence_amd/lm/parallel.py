@@ -202,6 +202,7 @@ class ParallelLLM(nn.Module):
         self._packed = None
         self._ws = None
         self._allowed = {}
+        self._allowed_hi = {}
         self._fp8_decode = False
         self._fp8_prefill = False
 
@@ -336,6 +337,7 @@ class ParallelLLM(nn.Module):
             io_name = "audio" if io_name == "discrete_audio" else io_name
             self.register_buffer(f"{io_name}_mask", mask[None, None].to(self.device))
         self._allowed = {}
+        self._allowed_hi = {}
 
     def _allowed_intervals(self, name: str):
         """Stream-0 allowed id runs of a mask buffer as a device int32 [n,2] tensor, plus whether every other
@@ -348,6 +350,7 @@ class ParallelLLM(nn.Module):
             iv = torch.stack([starts, ends], dim=1).to(torch.int32)
             pad_only = bool(((~m[1:]).sum(-1) == 1).all() and (~m[1:, 0]).all()) if self.num_stream > 1 else True
             self._allowed[name] = (iv.to(self.device).contiguous(), pad_only)
+            self._allowed_hi[name] = int(ends.max()) if len(ends) else 0
         return self._allowed[name]
 
     def _stream_intervals(self, name: str):
@@ -563,12 +566,16 @@ class ParallelLLM(nn.Module):
         # arguments, so ONE captured hipGraph of a step serves every token
         seq_pos = torch.full((B,), T0, dtype=torch.int32, device=self.device)
         step_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # every allowed id is below head_rows: the step need not stream the lm_head rows behind it (text decode: the 8 x 1025 audio-code
+        # rows, lm/parallel.py:557-568); status: raised by the device if an in-launch grid barrier of the step timed out
+        head_rows = self._allowed_hi.get(modality, 0)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws = self._workspace(B, 1, cache.cap)
         max_pos = T0 + max_step - 1                      # largest position this loop can append at
 
         def one_step():
             torch.ops.afhip.llm_decode_step(pk.blob, cache.k, cache.v, prev, out_tokens, finished, iv, self.eos_token_id, self.eot_token_id,
-                                            seq_pos, step_counter, max_pos, ws)
+                                            seq_pos, step_counter, max_pos, ws, head_rows, status)
 
         # a capture costs a device synchronise + allocator housekeeping (~ms): only worth it for loops long enough to amortise it
         use_graph = os.environ.get("AFHIP_DECODE_GRAPH", "1") != "0" and max_step >= 16 and not torch.cuda.is_current_stream_capturing()
@@ -593,6 +600,8 @@ class ParallelLLM(nn.Module):
             else:
                 one_step()
             if (step + 1) % poll == 0 or step == max_step - 1:
+                if int(status.item()) != 0:
+                    raise L.AfhipError("afhip_llm_decode_step: an in-launch grid barrier timed out (decode_chain.hip); tokens of this loop are undefined")
                 f = finished.cpu()
                 if bool((f >= 0).all()):
                     n_done = int(f.max()) + 1      # the reference leaves the loop right after this step (:512-513)

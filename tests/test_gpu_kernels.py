@@ -706,6 +706,59 @@ def test_gemm_skinny_swiglu_persistent_form_keeps_the_plain_forms_bits(fp8, M, H
     _check(outs[0], ref, 4e-2 + 4e-3 * float(ref.abs().max()), 3e-2, f"persistent swiglu fp8={fp8} M={M} H={H} I={I}")
 
 
+@pytest.mark.parametrize("case", ["qkv", "o", "down8", "down16", "down5", "lm_head", "lm_head16", "ragged_n", "m1", "small_k"])
+def test_gemm_stream_persistent_decode_form(case):
+    """gemm_stream.hip (the bf16 decode GEMMs: one persistent workgroup per CU, activations through LDS only -- whole image, or per-wave
+    slots when [M, K] does not fit) against the round-3 skinny kernels (AFHIP_SKINNY_STREAM=0) on the same operands and against fp32.
+    Plain-A launches must keep the old bits (same K order per row, same K-slice sum order); with the RMSNorm folded in, the row sum of
+    squares is now taken once per workgroup in staging order instead of per wave and step, so those agree to f32 rounding of the row scale."""
+    import ctypes as C
+    import os
+    from audio_intelligence_amd import _lib as L
+    lib = L.lib()
+    dt = torch.bfloat16
+    #            M   N      K      rms    bias   res    f32out
+    cfg = {"qkv": (8, 4608, 3584, True, True, False, False), "o": (8, 3584, 3584, False, False, True, False),
+           "down8": (8, 3584, 18944, False, False, True, False), "down16": (16, 3584, 18944, False, False, True, False),
+           "down5": (5, 1000, 18944, False, True, True, False), "lm_head": (8, 20520, 3584, True, False, False, True),
+           "lm_head16": (13, 20520, 1024, True, False, False, True), "ragged_n": (7, 3001, 1536, False, True, False, False),
+           "m1": (1, 4608, 3584, True, True, False, False), "small_k": (16, 9000, 512, False, False, True, True)}[case]
+    M, N, K, rms, bias, res, f32out = cfg
+    xd, xf = _q(_rand(M, K, seed=101) * 2.0, dt)
+    wd, wf = _q(_rand(N, K, seed=102, scale=0.05), dt)
+    gd, gf = _q(1 + 0.1 * _rand(K, seed=103), dt)
+    bd, bf = _q(_rand(N, seed=104, scale=0.1), dt)
+    rd, rf = _q(_rand(M, N, seed=105), dt)
+    outs = []
+    for stream in ("1", "0"):
+        os.environ["AFHIP_SKINNY_STREAM"] = stream
+        out = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else dt, device=_dev())
+        g = L.GemmArgs()
+        g.A, g.W, g.C = xd.data_ptr(), wd.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, N, K, K, K, N
+        g.dtype, g.out_f32 = L.dtype_code(dt), 1 if f32out else 0
+        if rms:
+            g.a_norm_w, g.a_norm_eps = gd.data_ptr(), 1e-6
+        if bias:
+            g.bias = bd.data_ptr()
+        if res:
+            g.residual, g.ldres = rd.data_ptr(), N
+        L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
+        outs.append(out.float().cpu())
+    os.environ.pop("AFHIP_SKINNY_STREAM")
+    h = xf
+    if rms:
+        h = gf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref = h @ wf.T + (bf if bias else 0) + (rf if res else 0)
+    assert torch.isfinite(outs[0]).all(), "the persistent form left output elements unwritten"
+    if rms:
+        _check(outs[0], outs[1], 2e-2 if not f32out else 2e-4, 1e-2 if not f32out else 1e-4, f"stream vs plain ({case})")
+    else:
+        assert torch.equal(outs[0], outs[1]), f"persistent and plain forms differ ({case})"
+    tol = (4e-2, 3e-2) if (rms or not f32out) else (2e-3 * float(ref.abs().max()), 1e-3)
+    _check(outs[0], ref, *tol, f"stream {case} {M}x{N}x{K}")
+
+
 def _ref_attention_exp2(qs, k, v, key_len=None):
     """q already carries head_dim^-0.5 * log2(e): P = 2^(q.k) normalised.  [B,T,H,hd] f32 -> [B,T,H*hd], softmax in f64."""
     B, T, H, hd = qs.shape
