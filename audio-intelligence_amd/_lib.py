@@ -42,7 +42,7 @@ class AttnArgs(C.Structure):
                 ("o_head_stride", C.c_longlong), ("key_split", C.c_int), ("partial_ws", C.c_void_p), ("partial_ws_bytes", C.c_size_t),
                 ("q_prescaled", C.c_int), ("new_k", C.c_void_p), ("new_v", C.c_void_p), ("new_kv_batch_stride", C.c_longlong),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("split_ticket", C.c_void_p), ("seq_pos", C.c_void_p), ("row_off", C.c_void_p),
-                ("out_fp8", C.c_int), ("out_scale_inv", C.c_float)]
+                ("out_fp8", C.c_int), ("out_scale_inv", C.c_float), ("out_img_rows", C.c_int)]
 
 
 class EncoderWeights(C.Structure):

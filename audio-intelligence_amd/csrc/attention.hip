@@ -43,6 +43,7 @@ struct AttnP {
     const int32_t* row_off; // packed (ragged) self-attention: sequence b's rows start at row row_off[b] of q / k / v / o and it has key_len[b]
                             // queries and keys; p.Tq / p.Tk are then only the upper bound that sized the grid.  NULL = [B, T] batches
     unsigned long long* dbg; // diagnostic: s_memtime stamps of workgroup 0 (AFHIP_ATTN_DBGPTR), normally NULL
+    int o_img_rows;         // split mode: the merge writes out[b, col] into a fragment-order image of this many rows (afhip.h: out_img_rows); 0 = plain rows
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -587,8 +588,16 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
         }
         for (; i < n; ++i) { l = fmaf(s_l[i], s_w[i], l); o = fmaf(p.part_o[slot_of(base + i) * HD + d], s_w[i], o); }
     }
+    const float y = l > 0.f ? o / l : 0.f;
+    if (p.o_img_rows > 0) {
+        // element (row b, column k) of the image the decode step's o projection streams (img_phase.h)
+        const int RM = p.o_img_rows, k = (int)((long long)qrow * p.ld_o + (long long)hq * p.o_hs) + d;
+        const long long off = (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + b) << 4) + ((k & 7) << 1);
+        *reinterpret_cast<T*>(p.o + off) = from_f32<T>(y);
+        return;
+    }
     T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
-    op[d] = from_f32<T>(l > 0.f ? o / l : 0.f);
+    op[d] = from_f32<T>(y);
 }
 
 }  // namespace
@@ -636,6 +645,9 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.ticket = a->key_split > 0 ? a->split_ticket : nullptr;
     p.seq_pos = a->seq_pos;
     p.row_off = a->row_off;
+    p.o_img_rows = a->out_img_rows;
+    if (a->out_img_rows) AFHIP_CHECK(a->key_split > 0 && a->split_ticket == nullptr && a->dtype == AFHIP_BF16 && (a->out_img_rows == 8 || a->out_img_rows == 16) && a->B <= a->out_img_rows,
+                                     "afhip_attention: out_img_rows (8 or 16, >= B) is a feature of the bf16 split-context (decode) form");
     if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
     if (a->seq_pos) AFHIP_CHECK(a->key_split > 0, "afhip_attention: seq_pos needs the split-context (decode) form, key_split > 0");
     if (a->new_k) {

@@ -1,0 +1,331 @@
+// Weight-streaming GEMM phase of the bf16 decode step whose activations arrive as a FRAGMENT-ORDER IMAGE in global memory
+// (M <= 16 rows, K % 512 == 0): C[M,N] = A'[M,K] . W[N,K]^T.
+//
+// stream_phase.h takes a row-major activation and pays for it in every workgroup: the same [8, 3584] rows are re-read, multiplied by
+// the RMSNorm gain and scattered into LDS 256 times per launch -- tools/stream_stamps.py: 5 of the 8.6 us of the q|k|v launch, before
+// the first MFMA.  Here the PRODUCER of an activation (the embedding, the o / down projection's residual epilogue, the SwiGLU epilogue,
+// the attention merge) writes it once in the order the MFMA A operand wants it,
+//     image[k / 64][half = (k >> 3) & 1][q = (k >> 4) & 3][row < RM][k & 7]          (RM * 128 bytes per 64-deep K step),
+// with the gain of the NEXT RMSNorm already applied (x stays available as plain rows for the residual adds), plus one partial sum of
+// squares per row and producing workgroup.  A consuming wave then loads its two A fragments of a K step with two contiguous
+// RM * 64-byte loads beside the weight loads (tools/micro/stream_shape.hip, A=frag: the rate of activations held in LDS to within a
+// few per cent), there is no staging pass, no LDS image, no barrier in front of the K loop; the RMSNorm row scale is
+// rsqrt(sum of the partials / K + eps) applied to the accumulator in the epilogue (Qwen2RMSNorm, modeling_qwen2.py:238-252).
+// One workgroup per CU walks its units (NT tiles of <= 16 weight rows) in one continuous weight stream, eight waves split K and
+// combine through LDS per unit -- as stream_phase.h.
+#pragma once
+#include "stream_phase.h"
+
+namespace stream {
+
+// byte offset of element (row m, column k) in a fragment-order image of RM rows
+__device__ __forceinline__ long long img_off(int RM, int m, int k) {
+    return (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + m) << 4) + ((k & 7) << 1);
+}
+
+// The phase descriptor (kernel argument).  A = the activation image; ss_in = [RM][ss_n] partial sums of squares of its rows (RMS only).
+struct ImgDesc {
+    const char* A; const char* W; const char* bias; const char* res; char* C;      // res / C: plain [M, N] rows (bf16; C f32 if out_f32), C may be NULL
+    const float* ss_in; int ss_n;
+    char* img_out; const char* img_gain; float* ss_out;                             // != NULL: the output also leaves as an image (x gain[n]) + partials [RM][grid]
+    int M, N, K; long long ldw, ldc, ldres; int out_f32; float eps; int tile_rows;
+    const int32_t* am_iv; int am_n_iv; float* am_val; int* am_idx;                  // greedy lm_head: argmax partials [RM][grid]
+#ifdef AFHIP_STREAM_STAMPS
+    unsigned long long* dbg;
+#endif
+};
+
+template <int NT, bool PAIR, bool RMS, int RM, int DEPTH, bool COH>
+struct ImgPhase {
+    static_assert(RM == 8 || RM == 16, "activation image rows");
+    static_assert(!PAIR || NT == 2, "SwiGLU pairs: one gate tile + one up tile");
+    static constexpr int NI = (NT * 256 + 511) / 512;               // epilogue items per thread
+    struct Regs { u32x4 w0[NT], w1[NT], a0, a1; };
+    ImgDesc p;
+    float* red;        // [2 unit parities][8 waves][NT tiles][64 lanes][4]
+    float* red_ss;     // [16] row sums of squares
+    float* am_v;       // [8 waves][4]
+    int* am_i;
+    int tid, lane, wave, c16, q, TR, gates, spw, my_units, total, cr;
+    const char* wrow[NT];
+    Regs r[DEPTH];
+    int sidx[DEPTH];
+    long long aofs;
+    int ig, iu, ij;
+    float ep_b[NI], ep_r[NI], ep_g[NI];
+    float ssp[2];      // this lane's share of the partial sums of squares of rows wave, wave + 8
+    f32x4 acc[NT];
+    int cu, cj;
+    float am_best, ss_acc;
+    int am_bi;
+
+    static constexpr size_t lds_bytes() { return (size_t)(2 * NW * NT * 256 + 16 + 64) * sizeof(float); }
+
+    template <typename T> static __device__ __forceinline__ T* opq(T* v) { asm volatile("" : "+s"(v)); return v; }
+    static __device__ __forceinline__ int opq(int v) { asm volatile("" : "+s"(v)); return v; }
+    static __device__ __forceinline__ long long opq(long long v) { asm volatile("" : "+s"(v)); return v; }
+    // field-by-field copy into scalar registers the compiler cannot re-derive from the kernel-argument segment (it re-read the
+    // descriptors with s_load + s_waitcnt in front of every weight load of a chain launch)
+    __device__ __forceinline__ ImgPhase(const ImgDesc& d, char* smem) {
+        p.A = opq(d.A); p.W = opq(d.W); p.bias = opq(d.bias); p.res = opq(d.res); p.C = opq(d.C);
+        p.ss_in = opq(d.ss_in); p.ss_n = opq(d.ss_n);
+        p.img_out = opq(d.img_out); p.img_gain = opq(d.img_gain); p.ss_out = opq(d.ss_out);
+        p.M = opq(d.M); p.N = opq(d.N); p.K = opq(d.K); p.ldw = opq(d.ldw); p.ldc = opq(d.ldc); p.ldres = opq(d.ldres);
+        p.out_f32 = opq(d.out_f32); p.eps = __int_as_float(opq(__float_as_int(d.eps))); p.tile_rows = opq(d.tile_rows);
+        p.am_iv = opq(d.am_iv); p.am_n_iv = opq(d.am_n_iv); p.am_val = opq(d.am_val); p.am_idx = opq(d.am_idx);
+#ifdef AFHIP_STREAM_STAMPS
+        p.dbg = opq(d.dbg);
+#endif
+        red = reinterpret_cast<float*>(smem);
+        red_ss = red + 2 * NW * NT * 256;
+        am_v = red_ss + 16;
+        am_i = reinterpret_cast<int*>(am_v + 32);
+    }
+
+    __device__ __forceinline__ void set_rows(int ui) {
+        const int u = (int)blockIdx.x + ui * (int)gridDim.x;
+        if constexpr (PAIR) {
+            int g = u * TR + cr;
+            g = g < gates ? g : gates - 1;
+            const long long n = ((long long)(g >> 5) << 6) + (g & 31);   // gate g = W row 64 (g >> 5) + (g & 31), its up row 32 further
+            wrow[0] = p.W + n * p.ldw * 2;
+            wrow[1] = wrow[0] + 32 * p.ldw * 2;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int n = (u * NT + t) * TR + cr;
+                n = n < p.N ? n : p.N - 1;
+                wrow[t] = p.W + (long long)n * p.ldw * 2;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue_a(Regs& x, int s) {
+        x.a0 = hld16<COH>(p.A, aofs + (long long)s * (RM * 128));
+        x.a1 = hld16<COH>(p.A, aofs + (long long)s * (RM * 128) + RM * 64);
+    }
+    template <bool WITH_A> __device__ __forceinline__ int issue(Regs& x) {
+        const int s = wave + NW * ij;
+        const long long koff = (long long)s * (KS * 2) + q * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
+        if constexpr (WITH_A) issue_a(x, s);
+        ++ig;
+        if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
+        return s;
+    }
+    // bias / residual / image gain of this thread's epilogue items (o = tid (+ 512): reg = o & 3, column = (o >> 2) & 15, row group =
+    // (o >> 6) & 3, tile = o >> 8), fetched when a unit STARTS.  In a chain the residual a thread adds is the element it wrote itself.
+    __device__ __forceinline__ void fetch_epi(int ui) {
+        if constexpr (!PAIR) {
+            const int u = (int)blockIdx.x + ui * (int)gridDim.x;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int o = tid + 512 * i;
+                const int reg = o & 3, ln = (o >> 2) & 63, nt = o >> 8;
+                const int n = (u * NT + nt) * TR + (ln & 15), m = 4 * (ln >> 4) + reg;
+                const bool ok = o < NT * 256 && (ln & 15) < TR && n < p.N && m < p.M;
+                const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional
+                ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
+                ep_g[i] = p.img_gain ? (float)reinterpret_cast<const bf16*>(p.img_gain)[nc] : 1.f;
+                ep_r[i] = p.res ? hld_bf16<COH>(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
+            }
+        }
+    }
+
+    // Indices and the first weight window.  A_READY = false: the image is still being written by other workgroups of this launch --
+    // only weights (and own-data residuals) move until run().
+    template <bool A_READY> __device__ __forceinline__ void begin() {
+        tid = threadIdx.x; lane = tid & 63; wave = tid >> 6;
+        c16 = lane & 15; q = lane >> 4;
+        TR = p.tile_rows;
+        gates = p.N >> 1;
+        const int n_units = PAIR ? (gates + TR - 1) / TR : (p.N + NT * TR - 1) / (NT * TR);
+        spw = p.K / (KS * NW);                                      // K steps per wave per unit (host: K % 512 == 0)
+        my_units = (n_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        if (my_units < 0) my_units = 0;
+        total = my_units * spw;
+        cr = c16 < TR ? c16 : TR - 1;                               // lanes past the share re-read its last row (same lines), their results are dropped
+        aofs = (long long)((q * RM + (c16 & (RM - 1))) << 4);
+        ST_STAMP(0);
+        ig = 0; iu = 0; ij = 0;
+        if (my_units > 0) set_rows(0);
+        // chained (A_READY = false): wave 0 is the wave that polls the grid barrier -- a poll's result retires in order BEHIND every
+        // vector load the wave has in flight, so with a weight window of its own it would see the barrier open only after that whole
+        // window had landed (3-5 us under the stream); it issues its window in run() instead
+        if (A_READY || wave != 0) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                sidx[d] = 0;
+                if (ig < total) sidx[d] = issue<A_READY>(r[d]);
+            }
+        }
+        ST_STAMP(1);
+        if (my_units > 0) fetch_epi(0);
+    }
+
+    __device__ __forceinline__ void finish_unit() {
+        float* rp = red + (cu & 1) * (NW * NT * 256);              // two buffers: the next unit's barrier orders the reuse
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            *reinterpret_cast<f32x4*>(rp + (((wave * NT + t) * 64 + lane) << 2)) = acc[t];
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (RMS) {
+            if (cu == 0) {                                          // the row sums of squares: this wave's two rows, once per phase
+#pragma unroll
+                for (int ri = 0; ri < RM / 8; ++ri) {
+                    const float t = wave_sum(ssp[ri]);
+                    if (lane == 0) red_ss[wave + 8 * ri] = t;
+                }
+            }
+        }
+        const int u = (int)blockIdx.x + cu * (int)gridDim.x;
+        __syncthreads();
+        if constexpr (PAIR) {
+            if (tid < 256) {
+                const int reg = tid & 3, ln = tid >> 2;
+                float g = 0.f, uu = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    g += rp[(((w * 2 + 0) * 64 + ln) << 2) + reg];
+                    uu += rp[(((w * 2 + 1) * 64 + ln) << 2) + reg];
+                }
+                const int mrow = 4 * (ln >> 4) + reg;
+                const int gi = u * TR + (ln & 15);
+                if ((ln & 15) < TR && gi < gates && mrow < p.M) {
+                    if constexpr (RMS) {
+                        const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.eps);
+                        g *= rs; uu *= rs;
+                    }
+                    const float y = silu(g) * uu;
+                    if (p.img_out) hst_bf16<COH>(p.img_out, img_off(RM, mrow, gi), y);
+                    else hst_bf16<COH>(p.C, ((long long)mrow * p.ldc + gi) * 2, y);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int o = tid + 512 * i;
+                if (o < NT * 256) {
+                    const int reg = o & 3, ln = (o >> 2) & 63, nt = o >> 8;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) v += rp[((((w * NT + nt) * 64) + ln) << 2) + reg];
+                    const int nn = (u * NT + nt) * TR + (ln & 15), mm = 4 * (ln >> 4) + reg;
+                    if ((ln & 15) < TR && nn < p.N && mm < p.M) {
+                        if constexpr (RMS) v *= rsqrtf(red_ss[mm] / (float)p.K + p.eps);
+                        if (p.bias) v += ep_b[i];
+                        if (p.res) v += ep_r[i];
+                        if (p.C) {
+                            if (p.out_f32) hst_f32<COH>(p.C, ((long long)mm * p.ldc + nn) * 4, v);
+                            else hst_bf16<COH>(p.C, ((long long)mm * p.ldc + nn) * 2, v);
+                        }
+                        if (p.img_out) {
+                            // the stored (bf16) value is what the next RMSNorm sees: gain applied to it, its square summed
+                            const float xb = (float)(bf16)v;
+                            hst_bf16<COH>(p.img_out, img_off(RM, mm, nn), xb * ep_g[i]);
+                            ss_acc += xb * xb;
+                        }
+                        if (p.am_val) {
+                            bool ok = false;
+                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= p.am_iv[2 * k] && nn < p.am_iv[2 * k + 1]);
+                            const float vb = (float)(bf16)v;           // the reference takes argmax over model-dtype logits
+                            if (ok && (vb > am_best || (vb == am_best && nn < am_bi))) { am_best = vb; am_bi = nn; }
+                        }
+                    }
+                }
+            }
+            if (cu + 1 < my_units) fetch_epi(cu + 1);
+        }
+    }
+
+    template <bool A_READY> __device__ __forceinline__ void run() {
+        if constexpr (!A_READY) {
+            if (wave != 0) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d)
+                    if (d < total) issue_a(r[d], sidx[d]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d)
+                    if (ig < total) issue<true>(r[d]);
+            }
+        }
+        if constexpr (RMS) {
+            // partial sums of squares of rows wave (and wave + 8): [row][ss_n], summed lane-strided here, across the wave at the first unit's end
+#pragma unroll
+            for (int ri = 0; ri < RM / 8; ++ri) {
+                float t = 0.f;
+                const int m = wave + 8 * ri;
+                for (int j = lane; j < p.ss_n; j += 64)
+                    t += __uint_as_float(COH ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + j) * 4, 0, 16)
+                                             : __float_as_uint(p.ss_in[m * p.ss_n + j]));
+                ssp[ri] = t;
+            }
+        }
+        ST_STAMP(2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cu = 0; cj = 0;
+        am_best = -INFINITY; am_bi = 0x7fffffff; ss_acc = 0.f;
+
+        for (int g0 = 0; g0 < total; g0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (g0 + d < total) {                               // workgroup-uniform: every wave has the same step count
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a0), __builtin_bit_cast(bf16x8, r[d].w0[t]), acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a1), __builtin_bit_cast(bf16x8, r[d].w1[t]), acc[t], 0, 0, 0);
+                    }
+                    if (g0 + d == 0) ST_STAMP(3);
+                    if (ig < total) issue<true>(r[d]);
+                    if (g0 + d == total - 1) ST_STAMP(4);
+                    if (++cj == spw) { finish_unit(); cj = 0; ++cu; }
+                }
+            }
+        }
+        ST_STAMP(5);
+        if constexpr (!PAIR) {
+            // this thread's epilogue items all belong to row 4 * ((tid >> 6) & 3) + (tid & 3): merge over the 16 columns (lane bits 2..5),
+            // then over the two waves that share a row group
+            if (p.ss_out) {
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) ss_acc += __shfl_xor(ss_acc, o, 64);
+                __syncthreads();
+                if (lane < 4) am_v[wave * 4 + lane] = ss_acc;
+                __syncthreads();
+                if (tid < RM) {
+                    const int w0 = tid >> 2, rg = tid & 3;
+                    float t = am_v[w0 * 4 + rg];
+                    if (NT * 256 > 256) t += am_v[(w0 + 4) * 4 + rg];
+                    hst_f32<COH>(reinterpret_cast<char*>(p.ss_out), ((long long)tid * (int)gridDim.x + (int)blockIdx.x) * 4, tid < p.M ? t : 0.f);
+                }
+            }
+            if (p.am_val) {
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) {
+                    const float ov = __shfl_xor(am_best, o, 64);
+                    const int oi = __shfl_xor(am_bi, o, 64);
+                    if (ov > am_best || (ov == am_best && oi < am_bi)) { am_best = ov; am_bi = oi; }
+                }
+                __syncthreads();
+                if (lane < 4) { am_v[wave * 4 + lane] = am_best; am_i[wave * 4 + lane] = am_bi; }
+                __syncthreads();
+                if (tid < 16 && tid < p.M) {
+                    const int w0 = tid >> 2, rg = tid & 3;          // row tid = 4 * w0 + rg lives in waves w0 and w0 + 4
+                    float b0 = am_v[w0 * 4 + rg];
+                    int i0 = am_i[w0 * 4 + rg];
+                    const float b1 = am_v[(w0 + 4) * 4 + rg];
+                    const int i1 = am_i[(w0 + 4) * 4 + rg];
+                    if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
+                    const long long slot = (long long)tid * (int)gridDim.x + (int)blockIdx.x;
+                    hst_f32<COH>(reinterpret_cast<char*>(p.am_val), slot * 4, b0);
+                    hst_f32<COH>(reinterpret_cast<char*>(p.am_idx), slot * 4, __int_as_float(i0));
+                }
+            }
+        }
+    }
+};
+
+}  // namespace stream

@@ -210,6 +210,7 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
     tot += align256((size_t)B * w->n_stream * sizeof(int64_t)) + align256((size_t)B * sizeof(int64_t));
     tot += align256((size_t)B * w->hidden * dtype_size(w->dtype)) * 2;
     tot += afhip_masked_argmax_workspace_bytes(B);
+    if (T == 1) tot += align256(afhip_decode_chain_scratch_bytes(w, B));     // decode_chain.hip: barrier words, argmax partials, activation images
     return tot;
 }
 
@@ -217,7 +218,7 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
 // share a kv head are the query rows of one workgroup, RoPE + the cache append ride inside the launch, the context is split into
 // key ranges over workgroups and merged (flash-decoding)
 static int layer_attention(const afhip_llm_weights* w, const LlmWs& ws, int l, int B, int T, int pos0, afhip_kv_cache* cache, const int32_t* seq_pos,
-                           bool decode_attn, hipStream_t s) {
+                           bool decode_attn, hipStream_t s, int out_img_rows = 0) {
     const int dt = w->dtype, nq = w->n_q, nkv = w->n_kv, hd = w->hd;
     const size_t sz = dtype_size(dt);
     const int qw = (nq + 2 * nkv) * hd, rep = nq / nkv;
@@ -244,7 +245,8 @@ static int layer_attention(const afhip_llm_weights* w, const LlmWs& ws, int l, i
         a.rope_sin = seq_pos ? w->rope_sin : w->rope_sin + (size_t)pos0 * (hd / 2);
         // the in-launch merge (a.split_ticket = ws.ticket + l * B * nkv) is correct and bit-identical but SLOWER here: 4.10 vs 3.76 ms
         // per 7B step -- 224 workgroups each paying an agent-scope release (L2 write-back) cost more than one 5-us combine launch
-        a.split_ticket = DECODE_IN_LAUNCH_MERGE ? ws.ticket + (size_t)l * B * nkv : nullptr;
+        a.split_ticket = (DECODE_IN_LAUNCH_MERGE && !out_img_rows) ? ws.ticket + (size_t)l * B * nkv : nullptr;
+        a.out_img_rows = out_img_rows;
     } else {
         a.Tq = T; a.n_q = nq; a.n_kv = nkv;
         a.ld_q = qw; a.q_head_stride = hd; a.q_batch_stride = (long long)T * qw;
@@ -422,29 +424,43 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     int64_t* tok = (int64_t*)(base + off); off += align256((size_t)B * sizeof(int64_t));
     char* emb = base + off; off += align256((size_t)B * H * sz);
     char* hid = base + off; off += align256((size_t)B * H * sz);
-    char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);
+    char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);      // `off` = start of the decode-chain scratch
     int rc;
     AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
-    if (w->qkv_w8 == nullptr && w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B) &&
-        (size_t)B * w->vocab * sizeof(float) >= afhip_decode_chain_scratch_bytes(B)) {
-        // bf16 weights, B <= 16: the dependent GEMMs of the step run as chains inside one launch per layer (decode_chain.hip); the
-        // attention launches stay between them.  The f32 logits region of the workspace is not used here: it holds the barrier words
-        // and the argmax partials
+    if (w->qkv_w8 == nullptr && w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B)) {
+        // bf16 weights, B <= 16: the GEMMs of the step are the persistent imaged phases of decode_chain.hip -- activations handed from
+        // producer to consumer as fragment-order images -- one launch each (mode 1) or chained behind in-launch grid barriers (mode 2);
+        // the attention launches stay between them and their merge writes the image the o phase reads
         AFHIP_CHECK(pos >= 0 && pos + 1 <= cache->cap && pos + 1 <= w->rope_max_pos && cache->B >= B && cache->k && cache->v,
                     "afhip_llm_decode_step: position %d exceeds the KV capacity %d / rope table %d, or cache batch %d < %d", pos, cache->cap, w->rope_max_pos, cache->B, B);
         AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_decode_step: head_dim %d unsupported", w->hd);
-        const LlmWs ws = carve(w, B, base, cache->cap);
-        if (hipMemsetAsync(logits, 0, 2048, s) != hipSuccess) { afhip_set_error("decode step: barrier memset failed"); return AFHIP_ERR_LAUNCH; }
+        LlmWs ws = carve(w, B, base, cache->cap);
+        char* scratch = base + off;
+        const bool chain = afhip_decode_chain_mode() >= 2;
+        // the grid-barrier words of the chained launches start every step at zero (one-phase launches have no barrier)
+        if (chain && hipMemsetAsync(scratch, 0, 2048, s) != hipSuccess) { afhip_set_error("decode step: barrier memset failed"); return AFHIP_ERR_LAUNCH; }
         afhip_chain_step c = {};
-        c.w = w; c.B = B; c.x = ws.x; c.qkv = ws.qkv; c.att = ws.att; c.act = ws.act; c.scratch = logits; c.st = st; c.step = step;
+        c.w = w; c.B = B; c.x = ws.x; c.qkv = ws.qkv; c.scratch = scratch; c.st = st; c.step = step; c.bar0 = 0;
         int rounds = 0;
-        c.layer = -1; c.bar0 = 0;
-        if ((rc = afhip_decode_chain_launch(c, s, &rounds))) return rc;
-        for (int l = 0; l < w->n_layers; ++l) {
+        auto launch = [&](int phases, int layer, int qkv_layer) -> int {
+            c.phases = phases; c.layer = layer; c.qkv_layer = qkv_layer;
+            const int r = afhip_decode_chain_launch(c, s, &rounds);
             c.bar0 += rounds;
-            if ((rc = layer_attention(w, ws, l, B, 1, pos, cache, st->seq_pos, true, s))) return rc;
-            c.layer = l;
-            if ((rc = afhip_decode_chain_launch(c, s, &rounds))) return rc;
+            return r;
+        };
+        ws.att = (char*)afhip_decode_chain_att_image(w, B, scratch);
+        const int L = w->n_layers;
+        if (chain) { if ((rc = launch(AFHIP_PH_EMBED | AFHIP_PH_QKV, 0, 0))) return rc; }
+        else { if ((rc = launch(AFHIP_PH_EMBED, 0, 0)) || (rc = launch(AFHIP_PH_QKV, 0, 0))) return rc; }
+        for (int l = 0; l < L; ++l) {
+            if ((rc = layer_attention(w, ws, l, B, 1, pos, cache, st->seq_pos, true, s, B <= 8 ? 8 : 16))) return rc;
+            const int tail = l + 1 < L ? AFHIP_PH_QKV : (AFHIP_PH_HEAD | AFHIP_PH_PICK);
+            if (chain) { if ((rc = launch(AFHIP_PH_O | AFHIP_PH_GU | AFHIP_PH_DOWN | tail, l, l + 1))) return rc; }
+            else {
+                if ((rc = launch(AFHIP_PH_O, l, 0)) || (rc = launch(AFHIP_PH_GU, l, 0)) || (rc = launch(AFHIP_PH_DOWN, l, 0))) return rc;
+                if (l + 1 < L) { if ((rc = launch(AFHIP_PH_QKV, l, l + 1))) return rc; }
+                else { if ((rc = launch(AFHIP_PH_HEAD, l, 0)) || (rc = launch(AFHIP_PH_PICK, l, 0))) return rc; }
+            }
         }
         return 0;
     }

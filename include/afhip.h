@@ -236,6 +236,10 @@ typedef struct {
      * A operand of the out-projection (afhip_gemm_args.a_scale_const = 1 / out_scale_inv), without a quantisation pass. */
     int out_fp8;
     float out_scale_inv;
+    /* split-context (decode) form, bf16 only: 8 or 16 (>= B) = `out` is not [B, n_q hd] rows but the fragment-order activation image
+     * of that many rows the decode step's o projection streams (element (b, k) at (k / 64) * rows * 128 + (((k >> 3) & 1) * 4 * rows +
+     * ((k >> 4) & 3) * rows + b) * 16 + (k & 7) * 2 bytes; csrc/img_phase.h).  0 = plain rows. */
+    int out_img_rows;
 } afhip_attn_args;
 int afhip_attention(const afhip_attn_args* args, void* stream);
 

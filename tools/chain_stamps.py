@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "audio-intelligence_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DAFHIP_STREAM_STAMPS"]
 objs = []
-for name in ("gemm_stream", "gemm_skinny", "decode_chain"):
+for name in ("gemm_stream", "gemm_skinny", "decode_chain"):   # every unit that sees SkinnyP / ImgDesc
     obj = f"/tmp/{name}_stamps.o"
     subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj], check=True)
     objs.append(obj)

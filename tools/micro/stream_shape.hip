@@ -125,42 +125,23 @@ int main() {
     }
     for (int rep = 0; rep < 2; ++rep) {
         printf("---- pass %d\n", rep);
-        // down projection: N 3584, K 18944, one 14-row share per CU
         run<0, 1, 1, 2>("down", 3584, 18944, 14, 256);
-        run<0, 1, 1, 4>("down", 3584, 18944, 14, 256);
         run<0, 2, 1, 2>("down", 3584, 18944, 14, 256);
-        run<0, 0, 1, 2>("down", 3584, 18944, 14, 256);
+        run<0, 2, 1, 4>("down", 3584, 18944, 14, 256);
+        run<0, 2, 1, 7>("down", 3584, 18944, 14, 256);
         run<0, 0, 1, 4>("down", 3584, 18944, 14, 256);
-        run<1, 1, 1, 2>("down", 3584, 18944, 14, 256);
-        run<1, 2, 1, 2>("down", 3584, 18944, 14, 256);
-        run<1, 2, 1, 4>("down", 3584, 18944, 14, 256);
-        run<1, 0, 1, 2>("down", 3584, 18944, 14, 256);
-        run<1, 0, 1, 4>("down", 3584, 18944, 14, 256);
-        run<1, 0, 1, 8>("down", 3584, 18944, 14, 256);
-        // o projection
         run<0, 1, 1, 2>("o", 3584, 3584, 14, 256);
-        run<0, 0, 1, 2>("o", 3584, 3584, 14, 256);
-        run<1, 0, 1, 2>("o", 3584, 3584, 14, 256);
-        run<1, 0, 1, 4>("o", 3584, 3584, 14, 256);
-        run<1, 0, 1, 7>("o", 3584, 3584, 14, 256);
-        // q|k|v
+        run<0, 2, 1, 2>("o", 3584, 3584, 14, 256);
+        run<0, 2, 1, 7>("o", 3584, 3584, 14, 256);
+        run<0, 0, 1, 7>("o", 3584, 3584, 14, 256);
         run<0, 1, 2, 2>("qkv", 4608, 3584, 9, 256);
-        run<0, 0, 2, 2>("qkv", 4608, 3584, 9, 256);
-        run<1, 0, 2, 2>("qkv", 4608, 3584, 9, 256);
-        run<1, 0, 2, 4>("qkv", 4608, 3584, 9, 256);
-        run<1, 0, 2, 7>("qkv", 4608, 3584, 9, 256);
-        // gate/up pairs, persistent
+        run<0, 2, 2, 4>("qkv", 4608, 3584, 9, 256);
+        run<0, 2, 2, 7>("qkv", 4608, 3584, 9, 256);
+        run<0, 0, 2, 7>("qkv", 4608, 3584, 9, 256);
+        run<0, 2, 2, 4>("gateup", 37890, 3584, 15, 256);
         run<0, 0, 2, 4>("gateup", 37890, 3584, 15, 256);
-        run<1, 0, 2, 4>("gateup", 37890, 3584, 15, 256);
-        run<1, 0, 2, 7>("gateup", 37890, 3584, 15, 256);
-        run<0, 0, 2, 4>("gateup", 37888, 3584, 16, 256);
-        run<1, 0, 2, 4>("gateup", 37888, 3584, 16, 256);
-        // lm_head: 160 520 rows -> 2508 units of 4 x 16
-        run<0, 1, 4, 2>("lm_head", 160512, 3584, 16, 0);
+        run<0, 2, 4, 2>("lm_head", 160512, 3584, 16, 256);
         run<0, 0, 4, 2>("lm_head", 160512, 3584, 16, 256);
-        run<1, 0, 4, 2>("lm_head", 160512, 3584, 16, 256);
-        run<1, 0, 4, 4>("lm_head", 160512, 3584, 16, 256);
-        run<1, 0, 4, 2>("lm_head", 160512, 3584, 16, 0);
     }
     return 0;
 }
