@@ -218,6 +218,15 @@ template <typename PH> void launch_phase(const ImgDesc& d, int grid, hipStream_t
         (void)hipFuncSetAttribute((const void*)img_phase_kernel<PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH::lds_bytes());
     hipLaunchKernelGGL((img_phase_kernel<PH>), dim3((unsigned)grid), dim3(512), PH::lds_bytes(), s, d);
 }
+template <int RM> void launch_single8(const ChainArgs& a, int cus, hipStream_t s) {      // e4m3 weights (W8A16)
+    switch (a.phases) {
+        case AFHIP_PH_O: launch_phase<ImgPhase<1, false, false, RM, 7, false, true>>(a.o, cus, s); break;
+        case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, 4, false, true>>(a.gu, cus, s); break;
+        case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, 7, false, true>>(a.down, cus, s); break;
+        case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, 4, false, true>>(a.qkv, cus, s); break;
+        default: launch_phase<ImgPhase<4, false, true, RM, 2, false, true>>(a.head, cus, s); break;
+    }
+}
 template <int RM> void launch_single(const ChainArgs& a, int cus, hipStream_t s) {
     switch (a.phases) {
         case AFHIP_PH_EMBED: hipLaunchKernelGGL(embed_kernel<RM>, dim3((unsigned)a.B), dim3(512), 0, s, a); break;
@@ -291,6 +300,7 @@ int afhip_decode_chain_launch(const afhip_chain_step& c, hipStream_t s, int* rou
     rounds = nph > 0 ? nph - 1 : 0;                               // one barrier between consecutive phases of the launch
     const int rpw_h = cdiv(H, cus);                              // one equal share of output rows per CU (gemm_skinny.hip)
     const int rpw_q = cdiv(qw, cus);
+    const bool f8 = w->qkv_w8 != nullptr;                        // W8A16 copies of the streamed weights (afhip.h): one-phase launches only
     if (c.phases & AFHIP_PH_EMBED) {
         a.prev_token = c.st->prev_token; a.table = (const char*)w->embed; a.x = c.x; a.ximg = ximg; a.gain = (const char*)w->ln1_w[0]; a.ss = xss; a.ss_n = cus;
         a.S = w->n_stream; a.H = H; a.vocab = w->vocab;
@@ -298,12 +308,14 @@ int afhip_decode_chain_launch(const afhip_chain_step& c, hipStream_t s, int* rou
     a.B = B;
     if (c.phases & AFHIP_PH_QKV) {
         const int l = c.qkv_layer;
-        fill(a.qkv, ximg, w->qkv_w[l], w->qkv_b[l], nullptr, c.qkv, B, qw, H, qw, 0, cdiv(rpw_q, 2), xss, cus, w->rms_eps);
+        fill(a.qkv, ximg, f8 ? w->qkv_w8[l] : w->qkv_w[l], w->qkv_b[l], nullptr, c.qkv, B, qw, H, qw, 0, cdiv(rpw_q, 2), xss, cus, w->rms_eps);
+        if (f8) a.qkv.w_scale = w->qkv_s[l];
     }
     if (c.phases & (AFHIP_PH_O | AFHIP_PH_GU | AFHIP_PH_DOWN)) {
         const int l = c.layer;
         // o: attention image -> x (+ residual), x image with the post-attention norm's gain, its sums of squares
-        fill(a.o, attimg, w->o_w[l], nullptr, c.x, c.x, B, H, AO, H, H, rpw_h, nullptr, 0, 0.f);
+        fill(a.o, attimg, f8 ? w->o_w8[l] : w->o_w[l], nullptr, c.x, c.x, B, H, AO, H, H, rpw_h, nullptr, 0, 0.f);
+        if (f8) a.o.w_scale = w->o_s[l];
         a.o.img_out = ximg; a.o.img_gain = (const char*)w->ln2_w[l]; a.o.ss_out = xss;
         // SwiGLU pairs: the TR <= 16 gate rows per unit whose ceil(units / CUs) * TR is smallest (gemm_skinny.hip)
         int best = 16, best_cost = cdiv(cdiv(I, 16), cus) * 16;
@@ -311,15 +323,19 @@ int afhip_decode_chain_launch(const afhip_chain_step& c, hipStream_t s, int* rou
             const int cost = cdiv(cdiv(I, tr), cus) * tr;
             if (cost < best_cost) { best_cost = cost; best = tr; }
         }
-        fill(a.gu, ximg, w->gu_w[l], nullptr, nullptr, nullptr, B, 2 * I, H, I, 0, best, xss, cus, w->rms_eps);
+        fill(a.gu, ximg, f8 ? w->gu_w8[l] : w->gu_w[l], nullptr, nullptr, nullptr, B, 2 * I, H, I, 0, best, xss, cus, w->rms_eps);
+        if (f8) a.gu.w_scale = w->gu_s[l];
         a.gu.img_out = actimg;
         // down: SwiGLU image -> x (+ residual), x image with the NEXT norm's gain (next layer's input norm, or the final norm)
-        fill(a.down, actimg, w->down_w[l], nullptr, c.x, c.x, B, H, I, H, H, rpw_h, nullptr, 0, 0.f);
+        fill(a.down, actimg, f8 ? w->down_w8[l] : w->down_w[l], nullptr, c.x, c.x, B, H, I, H, H, rpw_h, nullptr, 0, 0.f);
+        if (f8) a.down.w_scale = w->down_s[l];
         a.down.img_out = ximg; a.down.img_gain = (const char*)(l + 1 < w->n_layers ? w->ln1_w[l + 1] : w->norm_w); a.down.ss_out = xss;
     }
     if (c.phases & AFHIP_PH_HEAD) {
         const int rows = c.st->head_rows > 0 && c.st->head_rows < w->vocab ? c.st->head_rows : w->vocab;
-        fill(a.head, ximg, w->lm_head, nullptr, nullptr, nullptr, B, rows, H, 0, 0, 16, xss, cus, w->rms_eps);
+        const bool h8 = f8 && w->lm_head8 != nullptr;
+        fill(a.head, ximg, h8 ? w->lm_head8 : w->lm_head, nullptr, nullptr, nullptr, B, rows, H, 0, 0, 16, xss, cus, w->rms_eps);
+        if (h8) a.head.w_scale = w->lm_head_s;
         a.head.am_iv = c.st->allowed; a.head.am_n_iv = c.st->n_iv; a.head.am_val = am_val; a.head.am_idx = am_idx;
     }
     if (c.phases & AFHIP_PH_PICK) {
@@ -346,7 +362,11 @@ int afhip_decode_chain_launch(const afhip_chain_step& c, hipStream_t s, int* rou
         (void)hipFuncSetAttribute((const void*)decode_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds());
     }
     if (nph == 1) {
-        if (rm == 8) launch_single<8>(a, cus, s); else launch_single<16>(a, cus, s);
+        const bool gemm = (c.phases & (AFHIP_PH_O | AFHIP_PH_GU | AFHIP_PH_DOWN | AFHIP_PH_QKV | AFHIP_PH_HEAD)) != 0;
+        const bool w8 = gemm && f8 && !((c.phases & AFHIP_PH_HEAD) && w->lm_head8 == nullptr);
+        if (w8) { if (rm == 8) launch_single8<8>(a, cus, s); else launch_single8<16>(a, cus, s); }
+        else if (rm == 8) launch_single<8>(a, cus, s);
+        else launch_single<16>(a, cus, s);
     } else if (rm == 8) hipLaunchKernelGGL(decode_chain_kernel<8>, dim3((unsigned)cus), dim3(512), chain_lds(), s, a);
     else hipLaunchKernelGGL(decode_chain_kernel<16>, dim3((unsigned)cus), dim3(512), chain_lds(), s, a);
     AFHIP_LAUNCH_CHECK();

@@ -27,6 +27,7 @@ __device__ __forceinline__ long long img_off(int RM, int m, int k) {
 struct ImgDesc {
     const char* A; const char* W; const char* bias; const char* res; char* C;      // res / C: plain [M, N] rows (bf16; C f32 if out_f32), C may be NULL
     const float* ss_in; int ss_n;
+    const float* w_scale;                                                            // W8 phases: [N] f32 row scales of the e4m3 weight
     char* img_out; const char* img_gain; float* ss_out;                             // != NULL: the output also leaves as an image (x gain[n]) + partials [RM][grid]
     int M, N, K; long long ldw, ldc, ldres; int out_f32; float eps; int tile_rows;
     const int32_t* am_iv; int am_n_iv; float* am_val; int* am_idx;                  // greedy lm_head: argmax partials [RM][grid]
@@ -35,12 +36,17 @@ struct ImgDesc {
 #endif
 };
 
-template <int NT, bool PAIR, bool RMS, int RM, int DEPTH, bool COH>
+// W8: the weights are OCP e4m3 bytes with one f32 scale per output row (W8A16, gemm_skinny_fp8.hip): a K step is 128 deep so that a lane
+// still reads 32 contiguous bytes of its weight row; the 32 values are widened to bf16 in registers and meet the lane's four A fragments
+// -- chunks of the SAME bf16 image (64-step 2 s + (q >> 1), column group 2 (q & 1) + (c >> 1), half c & 1) -- in four MFMAs.  K / 128 need not
+// divide by the eight waves: wave w takes steps w, w + 8, ... of every unit and all of them meet at the unit's combine barrier.
+template <int NT, bool PAIR, bool RMS, int RM, int DEPTH, bool COH, bool W8 = false>
 struct ImgPhase {
     static_assert(RM == 8 || RM == 16, "activation image rows");
     static_assert(!PAIR || NT == 2, "SwiGLU pairs: one gate tile + one up tile");
     static constexpr int NI = (NT * 256 + 511) / 512;               // epilogue items per thread
-    struct Regs { u32x4 w0[NT], w1[NT], a0, a1; };
+    static constexpr int NA = W8 ? 4 : 2, KSTEP = W8 ? 128 : 64, WB = W8 ? 1 : 2;       // A fragments per step, K per step, bytes per weight
+    struct Regs { u32x4 w0[NT], w1[NT], a[NA]; };
     ImgDesc p;
     float* red;        // [2 unit parities][8 waves][NT tiles][64 lanes][4]
     float* red_ss;     // [16] row sums of squares
@@ -52,7 +58,7 @@ struct ImgPhase {
     int sidx[DEPTH];
     long long aofs;
     int ig, iu, ij;
-    float ep_b[NI], ep_r[NI], ep_g[NI];
+    float ep_b[NI], ep_r[NI], ep_g[NI], ep_s[NI];
     float ssp[2];      // this lane's share of the partial sums of squares of rows wave, wave + 8
     f32x4 acc[NT];
     int cu, cj;
@@ -68,7 +74,7 @@ struct ImgPhase {
     // descriptors with s_load + s_waitcnt in front of every weight load of a chain launch)
     __device__ __forceinline__ ImgPhase(const ImgDesc& d, char* smem) {
         p.A = opq(d.A); p.W = opq(d.W); p.bias = opq(d.bias); p.res = opq(d.res); p.C = opq(d.C);
-        p.ss_in = opq(d.ss_in); p.ss_n = opq(d.ss_n);
+        p.ss_in = opq(d.ss_in); p.ss_n = opq(d.ss_n); p.w_scale = opq(d.w_scale);
         p.img_out = opq(d.img_out); p.img_gain = opq(d.img_gain); p.ss_out = opq(d.ss_out);
         p.M = opq(d.M); p.N = opq(d.N); p.K = opq(d.K); p.ldw = opq(d.ldw); p.ldc = opq(d.ldc); p.ldres = opq(d.ldres);
         p.out_f32 = opq(d.out_f32); p.eps = __int_as_float(opq(__float_as_int(d.eps))); p.tile_rows = opq(d.tile_rows);
@@ -88,24 +94,31 @@ struct ImgPhase {
             int g = u * TR + cr;
             g = g < gates ? g : gates - 1;
             const long long n = ((long long)(g >> 5) << 6) + (g & 31);   // gate g = W row 64 (g >> 5) + (g & 31), its up row 32 further
-            wrow[0] = p.W + n * p.ldw * 2;
-            wrow[1] = wrow[0] + 32 * p.ldw * 2;
+            wrow[0] = p.W + n * p.ldw * WB;
+            wrow[1] = wrow[0] + 32 * p.ldw * WB;
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 int n = (u * NT + t) * TR + cr;
                 n = n < p.N ? n : p.N - 1;
-                wrow[t] = p.W + (long long)n * p.ldw * 2;
+                wrow[t] = p.W + (long long)n * p.ldw * WB;
             }
         }
     }
     __device__ __forceinline__ void issue_a(Regs& x, int s) {
-        x.a0 = hld16<COH>(p.A, aofs + (long long)s * (RM * 128));
-        x.a1 = hld16<COH>(p.A, aofs + (long long)s * (RM * 128) + RM * 64);
+        if constexpr (W8) {
+            // fragment c of lane q: image chunk (64-step 2 s + (q >> 1), column group 2 (q & 1) + (c >> 1), half c & 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                x.a[c] = hld16<COH>(p.A, aofs + (long long)s * (RM * 256) + (c & 1) * (RM * 64) + (c >> 1) * (RM * 16));
+        } else {
+            x.a[0] = hld16<COH>(p.A, aofs + (long long)s * (RM * 128));
+            x.a[1] = hld16<COH>(p.A, aofs + (long long)s * (RM * 128) + RM * 64);
+        }
     }
     template <bool WITH_A> __device__ __forceinline__ int issue(Regs& x) {
         const int s = wave + NW * ij;
-        const long long koff = (long long)s * (KS * 2) + q * 32;
+        const long long koff = (long long)s * 128 + q * 32;          // 32 bytes per lane and step in either weight format
 #pragma unroll
         for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
         if constexpr (WITH_A) issue_a(x, s);
@@ -128,6 +141,7 @@ struct ImgPhase {
                 ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
                 ep_g[i] = p.img_gain ? (float)reinterpret_cast<const bf16*>(p.img_gain)[nc] : 1.f;
                 ep_r[i] = p.res ? hld_bf16<COH>(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
+                ep_s[i] = W8 ? p.w_scale[nc] : 1.f;
             }
         }
     }
@@ -140,12 +154,14 @@ struct ImgPhase {
         TR = p.tile_rows;
         gates = p.N >> 1;
         const int n_units = PAIR ? (gates + TR - 1) / TR : (p.N + NT * TR - 1) / (NT * TR);
-        spw = p.K / (KS * NW);                                      // K steps per wave per unit (host: K % 512 == 0)
+        // K steps per wave per unit: bf16 K % 512 == 0 (host), every wave the same count; e4m3: wave w takes steps w, w + 8, ... of K / 128
+        spw = W8 ? (p.K / 128 - wave + 7) / 8 : p.K / (KS * NW);
         my_units = (n_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
         if (my_units < 0) my_units = 0;
         total = my_units * spw;
         cr = c16 < TR ? c16 : TR - 1;                               // lanes past the share re-read its last row (same lines), their results are dropped
-        aofs = (long long)((q * RM + (c16 & (RM - 1))) << 4);
+        aofs = W8 ? (long long)(q >> 1) * (RM * 128) + (long long)((((q & 1) * 2) * RM + (c16 & (RM - 1))) << 4)
+                  : (long long)((q * RM + (c16 & (RM - 1))) << 4);
         ST_STAMP(0);
         ig = 0; iu = 0; ij = 0;
         if (my_units > 0) set_rows(0);
@@ -197,6 +213,10 @@ struct ImgPhase {
                         const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.eps);
                         g *= rs; uu *= rs;
                     }
+                    if constexpr (W8) {
+                        const int ng = ((gi >> 5) << 6) + (gi & 31);
+                        g *= p.w_scale[ng]; uu *= p.w_scale[ng + 32];
+                    }
                     const float y = silu(g) * uu;
                     if (p.img_out) hst_bf16<COH>(p.img_out, img_off(RM, mrow, gi), y);
                     else hst_bf16<COH>(p.C, ((long long)mrow * p.ldc + gi) * 2, y);
@@ -214,6 +234,7 @@ struct ImgPhase {
                     const int nn = (u * NT + nt) * TR + (ln & 15), mm = 4 * (ln >> 4) + reg;
                     if ((ln & 15) < TR && nn < p.N && mm < p.M) {
                         if constexpr (RMS) v *= rsqrtf(red_ss[mm] / (float)p.K + p.eps);
+                        if constexpr (W8) v *= ep_s[i];
                         if (p.bias) v += ep_b[i];
                         if (p.res) v += ep_r[i];
                         if (p.C) {
@@ -272,11 +293,31 @@ struct ImgPhase {
         for (int g0 = 0; g0 < total; g0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                if (g0 + d < total) {                               // workgroup-uniform: every wave has the same step count
+                if (g0 + d < total) {                               // wave-uniform; every wave reaches each unit's combine barrier exactly once
+                    if constexpr (W8) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a0), __builtin_bit_cast(bf16x8, r[d].w0[t]), acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a1), __builtin_bit_cast(bf16x8, r[d].w1[t]), acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) {
+                            // widen this tile's 32 e4m3 weights: dword e of half h holds k = 16 h + 4 e .. + 4 -> bf16 chunk 2 h + (e >> 1)
+                            u32x4 wb[4];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                                    const uint32_t v = h ? r[d].w1[t][e] : r[d].w0[t][e];
+                                    wb[2 * h + (e >> 1)][2 * (e & 1)] = __builtin_bit_cast(uint32_t, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)v, 1.0f, false));
+                                    wb[2 * h + (e >> 1)][2 * (e & 1) + 1] = __builtin_bit_cast(uint32_t, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)v, 1.0f, true));
+                                }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a[c]), __builtin_bit_cast(bf16x8, wb[c]), acc[t], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a[0]), __builtin_bit_cast(bf16x8, r[d].w0[t]), acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[d].a[1]), __builtin_bit_cast(bf16x8, r[d].w1[t]), acc[t], 0, 0, 0);
+                        }
                     }
                     if (g0 + d == 0) ST_STAMP(3);
                     if (ig < total) issue<true>(r[d]);

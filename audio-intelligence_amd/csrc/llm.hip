@@ -427,7 +427,8 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);      // `off` = start of the decode-chain scratch
     int rc;
     AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
-    if (w->qkv_w8 == nullptr && w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B)) {
+    if (w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B) &&
+        (w->qkv_w8 == nullptr || (w->o_w8 && w->gu_w8 && w->down_w8 && w->qkv_s && w->o_s && w->gu_s && w->down_s && B <= 16))) {
         // bf16 weights, B <= 16: the GEMMs of the step are the persistent imaged phases of decode_chain.hip -- activations handed from
         // producer to consumer as fragment-order images -- one launch each (mode 1) or chained behind in-launch grid barriers (mode 2);
         // the attention launches stay between them and their merge writes the image the o phase reads
@@ -436,7 +437,7 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
         AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_decode_step: head_dim %d unsupported", w->hd);
         LlmWs ws = carve(w, B, base, cache->cap);
         char* scratch = base + off;
-        const bool chain = afhip_decode_chain_mode() >= 2;
+        const bool chain = afhip_decode_chain_mode() >= 2 && w->qkv_w8 == nullptr;      // the chained launches take bf16 weights only
         // the grid-barrier words of the chained launches start every step at zero (one-phase launches have no barrier)
         if (chain && hipMemsetAsync(scratch, 0, 2048, s) != hipSuccess) { afhip_set_error("decode step: barrier memset failed"); return AFHIP_ERR_LAUNCH; }
         afhip_chain_step c = {};
