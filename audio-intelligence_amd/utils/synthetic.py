@@ -102,3 +102,29 @@ def make_prompt(text_vocab: int, n: int = 16, seed: int = 7):
     """Synthetic text ids in [1, text_vocab) (no tokenizer offline)."""
     import numpy as np
     return np.random.default_rng(seed).integers(1, text_vocab, size=n).tolist()
+
+
+def make_offline_xcodec(seed: int = 1234):
+    """The X-codec network of the audio-output side with seeded random weights: `transformers.XcodecModel(XcodecConfig())` -- the class
+    the reference loads by tag (multimodal_io/audio.py:203-218), constructed offline from its default config (16 kHz, hop 320, 8 x 1024
+    codebooks).  The same call in the fixture script (oracle/make_golden_codec.py) and in the tests gives the same parameters as long as
+    torch / transformers are those of the image; `xcodec_fingerprint` detects a drift."""
+    import transformers
+    torch.manual_seed(seed)
+    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval()
+    # the residual-VQ codebooks are BUFFERS the constructor leaves at zero (they are learnt by k-means / EMA): with them at zero every
+    # frame encodes to entry 0 and the decoder ignores the codes.  Seeded entries make both directions depend on the codes.
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, buf in codec.named_buffers():
+        if name.endswith("codebook.embed") or name.endswith("codebook.embed_avg"):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.5)
+        elif name.endswith("codebook.inited"):
+            buf.fill_(1)
+        elif name.endswith("codebook.cluster_size"):
+            buf.fill_(1.0)
+    return codec
+
+
+def xcodec_fingerprint(codec) -> float:
+    """sum of |parameter| in float64: equal fingerprints <=> (practically) equal seeded weights"""
+    return float(sum(p.detach().double().abs().sum() for p in codec.parameters()) + sum(b.detach().double().abs().sum() for b in codec.buffers()))

@@ -187,8 +187,8 @@ def test_embed_tokenises_discrete_audio_on_the_fly():
         pytest.skip("transformers without XcodecModel")
     from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO
     model, _ = H.build_tiny_ualm(torch.float32, DEV)
-    torch.manual_seed(0)
-    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval().to(DEV)
+    from audio_intelligence_amd.utils.synthetic import make_offline_xcodec
+    codec = make_offline_xcodec(0).to(DEV)
     io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
     old = model.multimodal_io_dict["discrete_audio"]
     assert io.get_stream_interval() == old.get_stream_interval() and io.num_stream() == old.num_stream()
@@ -212,3 +212,55 @@ def test_embed_tokenises_discrete_audio_on_the_fly():
     model.multimodal_io_dict["discrete_audio"] = DiscreteAudioTokenIO()               # no tokeniser attached: a clear error, not silence
     with pytest.raises(RuntimeError):
         model._embed(ids.clone(), kw)
+
+
+def test_embed_on_the_fly_tokenisation_against_the_reference_class_ids():
+    """SURVEY 8f-4, codec leg on the GPU: `_embed`'s on-the-fly path (lm/parallel.py:233-257) with the seeded offline X-codec living on
+    the GPU, against the ids the REFERENCE's DiscreteAudioIO.encode_batch produced for the same clips (tests/golden/golden_codec.*,
+    oracle/make_golden_codec.py) -- not against itself.  The codec is a torch module: its GPU convolutions may round a residual-VQ
+    near-tie differently from the CPU run the fixture was captured on, so the ids are held to >= 99 % equality and `_embed` must equal
+    `_embed` on the golden ids placed by hand wherever they agree (every row of a clip whose ids all agree)."""
+    import json
+    import numpy as np
+    _need_gpu()
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "XcodecModel"):
+        pytest.skip("transformers without XcodecModel")
+    from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO
+    from audio_intelligence_amd.utils import synthetic as syn
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G = json.load(open(os.path.join(gold_dir, "golden_codec.json")))
+    A = np.load(os.path.join(gold_dir, "golden_codec_arrays.npz"))
+    codec = syn.make_offline_xcodec(G["codec_seed"])
+    if abs(syn.xcodec_fingerprint(codec) - G["fingerprint"]) > 1e-6 * G["fingerprint"]:
+        pytest.skip("the seeded offline X-codec differs from the one the fixture was captured with (torch / transformers version skew)")
+    model, _ = H.build_tiny_ualm(torch.float32, DEV)
+    io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec.to(DEV))
+    model.multimodal_io_dict["discrete_audio"] = io
+    g = torch.Generator().manual_seed(G["wav_seed"])
+    n0, n1 = G["n_samples"]
+    wav = (torch.randn(2, n0, 1, generator=g) * 0.1).to(DEV)
+    lengths = torch.tensor([n0, n1])
+    gold_ids = torch.from_numpy(A["encode_ids"]).long()                    # [2, T, 8] in the IO's own vocabulary
+    T = gold_ids.shape[1]
+    with torch.no_grad():
+        got_ids = io.encode_batch(wav, lengths.to(DEV)).cpu()
+    same = (got_ids == gold_ids)
+    frac = float(same.float().mean())
+    print(f"on-the-fly ids equal to the reference's: {int(same.sum())} of {same.numel()}")
+    assert got_ids.shape == gold_ids.shape and frac >= 0.99
+    base = model.vocab_intervals["discrete_audio"][0][0]
+    ids = torch.zeros(2, T + 6, 8, dtype=torch.long)
+    ids[:, :, 0] = torch.randint(0, model.vocab_intervals["text"][0][1], (2, T + 6), generator=g)
+    kw = {"discrete_audio_feats": wav, "discrete_audio_lengths": lengths, "discrete_audio_indices": torch.tensor([[0, 3, T], [1, 2, T]])}
+    got = model._embed(ids.clone(), kw)
+    by_hand = ids.clone()
+    by_hand[0, 3:3 + T] = gold_ids[0] + base
+    by_hand[1, 2:2 + T] = gold_ids[1] + base
+    want = model._embed(by_hand, {})
+    rows_ok = torch.ones(2, T + 6, dtype=torch.bool)
+    rows_ok[0, 3:3 + T] = same[0].all(-1)
+    rows_ok[1, 2:2 + T] = same[1].all(-1)
+    assert torch.equal(got[rows_ok.to(got.device)], want[rows_ok.to(want.device)])
+    assert int(rows_ok.sum()) >= int(0.95 * rows_ok.numel())
+

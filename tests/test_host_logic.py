@@ -296,8 +296,8 @@ def test_discrete_audio_decode_batch_through_an_offline_xcodec():
     if not hasattr(transformers, "XcodecModel"):
         pytest.skip("transformers without XcodecModel")
     from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO, delay_interleave
-    torch.manual_seed(0)
-    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval()
+    from audio_intelligence_amd.utils.synthetic import make_offline_xcodec
+    codec = make_offline_xcodec(0)        # seeded weights AND seeded residual-VQ codebooks (the constructor leaves those at zero)
     assert codec.config.sample_rate == 16000 and codec.config.hop_length == 320 and codec.config.codebook_size == 1024
     io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
     g = torch.Generator().manual_seed(1)
@@ -317,6 +317,54 @@ def test_discrete_audio_decode_batch_through_an_offline_xcodec():
     assert torch.equal(back, codes) and lens.tolist() == [T, T]
 
 
+def test_discrete_audio_io_matches_the_reference_class_fixture():
+    """SURVEY 8f-4, codec leg, PINNED: tests/golden/golden_codec.* were captured from the reference's own
+    `DiscreteAudioIO(codec_choice="Xcodec", delay_interleave=True, _skip_loading=True)` (multimodal_io/audio.py:80-140) with the seeded
+    offline X-codec attached (oracle/make_golden_codec.py): its find_length (:656-672), encode_batch (:416-492: whole-frame trim, first
+    channel, bandwidth, offset + 1, replicate pad, delay interleave, a shorter clip in the batch) and decode_batch / _codec_decode_batch
+    (:494-596: de-interleave, offsets removed, pad ids -> entry 0, [B, S, T], lengths x hop).  DiscreteAudioTokenIO must reproduce the ids
+    exactly and the waveforms to float rounding."""
+    import json
+    import os
+    import numpy as np
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "XcodecModel"):
+        pytest.skip("transformers without XcodecModel")
+    from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO
+    from audio_intelligence_amd.utils import synthetic as syn
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G = json.load(open(os.path.join(gold_dir, "golden_codec.json")))
+    A = np.load(os.path.join(gold_dir, "golden_codec_arrays.npz"))
+    codec = syn.make_offline_xcodec(G["codec_seed"])
+    if abs(syn.xcodec_fingerprint(codec) - G["fingerprint"]) > 1e-6 * G["fingerprint"]:
+        pytest.skip("the seeded offline X-codec differs from the one the fixture was captured with (torch / transformers version skew)")
+    io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
+    assert io.sample_rate == G["sample_rate"] and io.frame_shift == G["frame_shift"] and io.codec_bandwidth == G["bandwidth"]
+    assert io.num_stream() == G["num_stream"] and [list(iv) for iv in io.get_stream_interval()] == G["stream_intervals"]
+    assert len(io.get_vocabulary()) == G["vocab_size"]
+    for n, sr, want in G["find_length"]:
+        assert io.find_length((np.zeros((1, n), np.float32), sr)) == want, (n, sr)
+    g = torch.Generator().manual_seed(G["wav_seed"])
+    n0, n1 = G["n_samples"]
+    wav = torch.randn(2, n0, 1, generator=g) * 0.1
+    step = G["sample_step"]
+    with torch.no_grad():
+        ids = io.encode_batch(wav, torch.tensor([n0, n1]))
+        gold_ids = torch.from_numpy(A["encode_ids"]).long()
+        assert ids.shape == gold_ids.shape and torch.equal(ids, gold_ids), f"{int((ids != gold_ids).sum())} ids differ from the reference's"
+        T = gold_ids.shape[1]
+        audio, alen, sr = io.decode_batch(gold_ids, torch.tensor([T, n1 // 320 + 7]))
+        assert list(audio.shape) == G["decode_audio_shape"] and [int(x) for x in alen] == G["decode_lengths"] and sr == G["decode_sample_rate"]
+        assert float((audio[:, 0, ::step] - torch.from_numpy(A["decode_audio_sample"])).abs().max()) <= 1e-5
+        for b in range(2):
+            assert abs(float(audio[b].double().sum()) - G["decode_audio_sum"][b]) <= 1e-3 * max(1.0, abs(G["decode_audio_sum"][b]))
+        audio2, alen2, _ = io.decode_batch(torch.from_numpy(A["pad_ids"]).long(), torch.tensor([T, T]))
+        assert [int(x) for x in alen2] == G["pad_lengths"]
+        assert float((audio2[:, 0, ::step] - torch.from_numpy(A["pad_audio_sample"])).abs().max()) <= 1e-5
+        assert float((audio2 - audio).abs().max()) > 1e-4          # the pad entries really changed the waveform (decoded as entry 0)
+
+
 def test_discrete_audio_encode_batch_through_an_offline_xcodec():
     """audio.py:417-491 (codec-only configuration) with the offline X-codec: wav [B, samples, 1] -> ids in the IO's vocabulary, delay
     interleaved.  Expected = the codec called directly (audio.py:641-654: first channel, trimmed to whole frames, the target bandwidth
@@ -326,8 +374,8 @@ def test_discrete_audio_encode_batch_through_an_offline_xcodec():
     if not hasattr(transformers, "XcodecModel"):
         pytest.skip("transformers without XcodecModel")
     from audio_intelligence_amd.multimodal_io.audio import DiscreteAudioTokenIO, delay_interleave
-    torch.manual_seed(0)
-    codec = transformers.XcodecModel(transformers.XcodecConfig()).eval()
+    from audio_intelligence_amd.utils.synthetic import make_offline_xcodec
+    codec = make_offline_xcodec(0)        # seeded weights AND seeded residual-VQ codebooks (the constructor leaves those at zero)
     io = DiscreteAudioTokenIO(n_stream=8, codebook_size=1024).attach_codec(codec)
     assert io.codec_bandwidth == 4 and io.frame_shift == 320
     g = torch.Generator().manual_seed(2)
