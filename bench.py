@@ -23,6 +23,7 @@ kernel's HBM figure and an AF3-7B-shape greedy-decode leg (decode tokens/s, the 
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -62,37 +63,81 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n, argv, extra_env=None, timeout=None):
+def _pdeathsig():
+    """preexec hook of a rank: SIGTERM when the launcher dies (Linux PR_SET_PDEATHSIG), so a launcher killed with SIGKILL -- which no
+    handler can see -- still takes its ranks with it; a rank blocked in an RCCL barrier would otherwise keep its GPU"""
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)       # PR_SET_PDEATHSIG = 1
+    except Exception:       # noqa: BLE001 -- best effort; the handlers below cover SIGTERM / SIGINT
+        pass
+
+
+def spawn_ranks(n, argv, extra_env=None, timeout=3600.0):
     """Start `n` fresh processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run sets
     them), wait for all of them, return the worst exit code.  The caller has not touched the GPU: children are ordinary
-    fork + exec of an uninitialised parent.  If a rank dies the others are ended by PID (they would wait at a barrier for ever)."""
+    fork + exec of an uninitialised parent.  If a rank dies the others are ended by PID (they would wait at a barrier for ever).
+    Like torch.distributed.run, the launcher never leaves ranks behind: SIGTERM / SIGINT to the launcher, an exception, or the
+    timeout (exit code 124) terminate, then kill, the exact PIDs it started; each rank also asks the kernel for SIGTERM should the
+    launcher die without running any of that."""
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "AFHIP_BENCH_SPAWNED": "1"})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    t0 = time.time()
-    rc, alive = 0, list(procs)
-    while alive:
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0:
-                rc = rc or (code if code > 0 else 128 - code)
-                for q in alive:                                      # exact PIDs we started
-                    q.terminate()
-        if timeout is not None and time.time() - t0 > timeout:
-            for q in alive:
+
+    def reap(grace=5.0):
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.time() + grace
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
                 q.kill()
-            rc = rc or 124
-        time.sleep(0.05)
+        for q in procs:
+            try:
+                q.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "AFHIP_BENCH_SPAWNED": "1"})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, preexec_fn=_pdeathsig))
+        t0 = time.time()
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0:
+                    rc = rc or (code if code > 0 else 128 - code)
+                    for q in alive:                                      # exact PIDs we started
+                        q.terminate()
+            if alive and timeout is not None and time.time() - t0 > timeout:
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    except _Stop as e:
+        rc = 128 + int(e.args[0])
+    finally:
+        reap()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 

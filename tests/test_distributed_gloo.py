@@ -158,6 +158,64 @@ def test_bench_launcher_reports_a_failed_rank():
     assert rc == 7 and _t.time() - t0 < 30
 
 
+def test_bench_launcher_takes_its_ranks_with_it_when_it_is_signalled_or_times_out():
+    """a launcher that is SIGTERMed (a driver timeout) or whose own timeout fires must not leave rank processes behind --
+    a rank blocked in an RCCL barrier would keep its GPU.  A tiny launcher process calls bench.spawn_ranks on ranks that write their PID
+    and sleep; after SIGTERM to the launcher (and, separately, after the launcher's timeout) none of those PIDs is alive."""
+    import signal
+    import subprocess
+    import sys
+    import tempfile
+    import time as _t
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        rank_py = os.path.join(tmp, "rank.py")
+        with open(rank_py, "w") as f:
+            f.write("import os,time\nopen(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n" % tmp)
+        launcher = ("import sys, os\nsys.path.insert(0, %r)\nimport bench\nreal = bench.os.path.abspath\n"
+                    "bench.os.path.abspath = lambda p: %r if p == bench.__file__ else real(p)\n"
+                    "sys.exit(bench.spawn_ranks(2, [], timeout=float(sys.argv[1])))\n" % (root, rank_py))
+
+        def pids():
+            out = []
+            for r in range(2):
+                fn = os.path.join(tmp, f"pid{r}")
+                if os.path.exists(fn) and open(fn).read().strip():
+                    out.append(int(open(fn).read()))
+            return out
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            # a zombie still answers kill(0): look at its state
+            try:
+                return open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+            except FileNotFoundError:
+                return False
+
+        for mode in ("sigterm", "timeout"):
+            for r in range(2):
+                fn = os.path.join(tmp, f"pid{r}")
+                if os.path.exists(fn):
+                    os.unlink(fn)
+            p = subprocess.Popen([sys.executable, "-c", launcher, "600" if mode == "sigterm" else "2"])
+            t0 = _t.time()
+            while len(pids()) < 2 and _t.time() - t0 < 60:
+                _t.sleep(0.05)
+            ranks = pids()
+            assert len(ranks) == 2 and all(alive(x) for x in ranks)
+            if mode == "sigterm":
+                p.send_signal(signal.SIGTERM)
+            rc = p.wait(timeout=60)
+            assert rc == (128 + signal.SIGTERM if mode == "sigterm" else 124), (mode, rc)
+            t1 = _t.time()
+            while any(alive(x) for x in ranks) and _t.time() - t1 < 10:
+                _t.sleep(0.05)
+            assert not any(alive(x) for x in ranks), f"{mode}: rank processes survived the launcher"
+
+
 def test_gather_with_rank_local_blocks_matches_full_upload():
     """encode_windows_sharded(total_windows=W) -- every rank hands in only its own block -- equals the form where every rank
     holds all windows (world size 2, ragged: 5 windows)."""
