@@ -349,10 +349,21 @@ class AFWhisperEncoder(nn.Module):
         mel_btc = ops.transpose_cast(x.contiguous(), self.dtype)
         if feat_len is None and attention_mask is not None:
             feat_len = (attention_mask[:, 0, 0, :] == 0).sum(-1)
-        out = self.encode_btc(mel_btc, feat_len)
+        states = None
+        if output_hidden_states:
+            # modeling_whisper.py:699-750: the input of every layer (entry 0 = conv stem + positions), then the pooled, normed output.
+            # The fused forward keeps one intermediate state per call (`hidden_layer`), so this debugging feature costs one forward per
+            # layer; the states come back in the model dtype, as the reference's do.
+            hs = []
+            for i in range(self.config.encoder_layers):
+                out, h = self.encode_btc(mel_btc, feat_len, hidden_layer=i - 1)
+                hs.append(h)
+            states = tuple(hs) + (out,)
+        else:
+            out = self.encode_btc(mel_btc, feat_len)
         if return_dict is False:
-            return (out,)
-        return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)
+            return tuple(v for v in (out, states) if v is not None)
+        return SimpleNamespace(last_hidden_state=out, hidden_states=states, attentions=None)
 
 
 class Qwen2AudioMultiModalProjector(nn.Module):

@@ -118,6 +118,14 @@ def test_tiny_encoder_f32_stages_conventions_and_golden():
         # reference forward signature: [B,128,3000] (+ additive 4-D mask)
         o2 = enc(mel.to(DEV)).last_hidden_state
         assert _maxerr(o2, ref) <= 2e-4
+        # output_hidden_states (modeling_whisper.py:699-750): the input of every layer, then the pooled + normed output
+        full = enc(mel.to(DEV), output_hidden_states=True)
+        assert len(full.hidden_states) == cfg["encoder_layers"] + 1 and torch.equal(full.last_hidden_state, o2)
+        for i in range(cfg["encoder_layers"]):
+            assert _maxerr(full.hidden_states[i], states[i]) <= 2e-4, f"hidden state {i}"
+        assert torch.equal(full.hidden_states[-1], o2)
+        tup = enc(mel.to(DEV), output_hidden_states=True, return_dict=False)
+        assert len(tup) == 2 and torch.equal(tup[0], o2) and len(tup[1]) == cfg["encoder_layers"] + 1
         after = g["tiny_encoder"][name]["after"]
         pipe = io.encode_batch(btc, torch.tensor([3000]))[0]
         assert pipe.shape[0] == 750 and torch.equal(pipe, out[0])
