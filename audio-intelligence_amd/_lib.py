@@ -96,6 +96,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "afhip_version": (_I, []),
     "afhip_last_error": (C.c_char_p, []),
+    "afhip_set_option": (_I, [C.c_char_p, _I]),
     "afhip_log_mel_tables_bytes": (_Z, []),
     "afhip_log_mel_tables_host": (_I, [_P, _P]),
     "afhip_log_mel_workspace_bytes": (_Z, [_I]),

@@ -498,8 +498,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         __syncthreads();                                                   // ... and every wave's
         int* flag = reinterpret_cast<int*>(smem);                          // the K/V tiles are dead: their LDS carries the verdict
         if (tid == 0) {
-            // (no release fence: every partial byte went out as an sc1 store and every storing wave drained vmcnt before the barrier above)
-            const int tk = __hip_atomic_fetch_add(p.ticket + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the ticket is an agent-scope RELEASE: it orders this workgroup's partial stores (already write-through and drained) before the
+            // count another XCD's merging workgroup acquires on -- the relaxed form worked on gfx950 but was a data race under the HSA memory
+            // model.  This path is not the default (option DECODE_MERGE): the separate merge launch is faster.
+            const int tk = __hip_atomic_fetch_add(p.ticket + hb, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             flag[0] = (tk == n_live - 1) ? 1 : 0;
         }
         __syncthreads();
@@ -643,7 +645,6 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 }  // namespace
 
 bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s);   // attention_enc.hip: the one-wave-per-SIMD encoder form
-bool afhip_attention_enc64x8(const afhip_attn_args* a, hipStream_t s); // attention_enc8.hip: the two-waves-per-SIMD encoder form (AFHIP_ATTN_ENC8=0: off)
 
 extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_attention: null args");
@@ -663,7 +664,6 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     if (a->causal) AFHIP_CHECK(a->q_pos0 >= 0 && a->q_pos0 + a->Tq <= a->Tk, "afhip_attention: causal needs q_pos0+Tq <= Tk (%d+%d vs %d)", a->q_pos0, a->Tq, a->Tk);
 
     if (a->row_off) AFHIP_CHECK(a->key_split == 0 && !a->causal && a->key_len && a->Tq == a->Tk, "afhip_attention: row_off (packed batches) needs key_len, Tq == Tk, no causal mask, no key_split");
-    if (afhip_attention_enc64x8(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
     if (afhip_attention_enc64(a, (hipStream_t)stream)) { AFHIP_LAUNCH_CHECK(); return 0; }
     AFHIP_CHECK(!a->out_fp8, "afhip_attention: out_fp8 is a feature of the encoder form (bf16, head_dim 64, q_prescaled, non-causal, no key split)");
 
@@ -694,7 +694,11 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         AFHIP_CHECK(a->key_split > 0 && a->new_v && a->rope_cos && a->rope_sin, "afhip_attention: fused RoPE/append needs key_split > 0, new_v and the cos/sin rows");
         AFHIP_CHECK(((uintptr_t)a->new_k % 16) == 0 && ((uintptr_t)a->new_v % 16) == 0 && (a->new_kv_batch_stride * sz) % 16 == 0, "afhip_attention: new_k / new_v must keep 16-byte alignment");
     }
+#ifdef AFHIP_ATTN_STAMPS   /* diagnostic build only (tools/attn_stamps.py) */
     { const char* dp = getenv("AFHIP_ATTN_DBGPTR"); p.dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr; }
+#else
+    p.dbg = nullptr;
+#endif
     if (a->key_split > 0) {
         AFHIP_CHECK(a->key_split % KT == 0, "afhip_attention: key_split must be a multiple of %d", KT);
         AFHIP_CHECK(a->Tq <= 32 && !a->causal, "afhip_attention: key_split needs Tq <= 32 and causal == 0");
@@ -709,10 +713,9 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
     p.n_xt = a->key_split > 0 ? n_split : cdiv(a->Tq, QT);
     AFHIP_CHECK((long long)p.n_xt * a->n_q * a->B < (1ll << 31), "afhip_attention: grid too large");
     const dim3 grid((unsigned)(p.n_xt * a->n_q * a->B)), block(256);
-    static int nbuf = -1;
-    if (nbuf < 0) { const char* e = getenv("AFHIP_ATTN_NBUF"); nbuf = (e && e[0] == '1') ? 1 : 2; }   // A/B switch
+    const int nbuf = afhip_opt(AFHIP_OPT_ATTN_NBUF) == 1 ? 1 : 2;   // A/B switch
     size_t lds = (size_t)nbuf * 2 * KT * a->hd * sz;     // stages of (K tile + V tile)
-    { static long pad = -1; if (pad < 0) { const char* e = getenv("AFHIP_ATTN_LDS_PAD"); pad = e ? atol(e) : 0; } lds += (size_t)pad; }   // occupancy experiment
+    lds += (size_t)(afhip_opt(AFHIP_OPT_ATTN_LDS_PAD) > 0 ? afhip_opt(AFHIP_OPT_ATTN_LDS_PAD) : 0);   // occupancy experiment
     {
         static unsigned long long attr_done = 0;
         if (afhip_first_use_on_device(&attr_done)) {
@@ -728,8 +731,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         if (nbuf == 2) hipLaunchKernelGGL((attn_kernel<TT, HH, 2>), grid, block, lds, s, p);             \
         else hipLaunchKernelGGL((attn_kernel<TT, HH, 1>), grid, block, lds, s, p);                        \
     } while (0)
-    static int lag = -1;
-    if (lag < 0) { const char* e = getenv("AFHIP_ATTN_LAG"); lag = (e && e[0] == '0') ? 0 : 1; }   // A/B switch
+    const int lag = afhip_opt(AFHIP_OPT_ATTN_LAG) != 0;   // A/B switch
     if (a->dtype == AFHIP_BF16 && a->hd == 64 && a->q_prescaled && a->key_split == 0 && nbuf == 2 && lag) {
         hipLaunchKernelGGL((attn_kernel<bf16, 64, 2, true>), grid, block, lds, s, p);      // lagged-maximum softmax (encoder, LayerNorm-folded mode)
     } else if (a->dtype == AFHIP_BF16) {

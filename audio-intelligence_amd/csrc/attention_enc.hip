@@ -103,18 +103,9 @@ constexpr int A_OA = 0, A_OB = 32, A_QA = 64, A_QB = 80, A_KF = 96, A_VF = 160;
 #define E_ACC_READ(DST, IDX) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(DST) : "n"(IDX))
 // MFMA forms (KF / Q / VF / O = first register of the operand's tuple in the accumulator file).  S_FIRST opens a chain from the VGPR tuple
 // C (written by VALU code shortly before: s_nop 1); the others accumulate in place.
-#if defined(E_TIMING_S_AGPR) || defined(E_TIMING_NOEXP) || defined(E_TIMING_NOADD) || defined(E_TIMING_NOCVT)
-#define E_REBASE_COND(PS) (__any((PS) == -12345.f))
-#else
 #define E_REBASE_COND(PS) (__any(!((PS) <= E_LAG_LIMIT)))
-#endif
-#ifdef E_TIMING_S_AGPR   /* TIMING EXPERIMENT ONLY (wrong results): the S' chains accumulate into a[224:239] instead of VGPRs */
-#define E_MFMA_S_FIRST(S, KF, Q, C) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[224:239], a[%2:%3], a[%4:%5], a[224:239]" : "+v"(S) : "v"(C), "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
-#define E_MFMA_S_ACC(S, KF, Q) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], a[%1:%2], a[%3:%4], a[224:239]" : "+v"(S) : "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
-#else
 #define E_MFMA_S_FIRST(S, KF, Q, C) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%2:%3], a[%4:%5], %1" : "=&v"(S) : "v"(C), "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
 #define E_MFMA_S_ACC(S, KF, Q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%1:%2], a[%3:%4], %0" : "+v"(S) : "n"(KF), "n"((KF) + 3), "n"(Q), "n"((Q) + 3))
-#endif
 #define E_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 a[%1:%2], a[%3:%4], %0, a[%1:%2]" :: "v"(PF), "n"(O), "n"((O) + 15), "n"(VF), "n"((VF) + 3) : "memory")
 // S' chains of one block from K set KSET (Q = first register of the block's Q fragments)
 #define E_CHAINS(S, KSET, Q, C)                                                              \
@@ -151,10 +142,8 @@ constexpr int A_OA = 0, A_OB = 32, A_QA = 64, A_QB = 80, A_KF = 96, A_VF = 160;
 #define E_READ_VH(SET, I, H, STAGE) asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%3" :: "v"(vaddr[(I) & 1]), \
                                              "n"(A_VF + (SET) * 32 + (I) * 4 + 2 * (H)), "n"(A_VF + (SET) * 32 + (I) * 4 + 2 * (H) + 1), \
                                              "n"((STAGE) * E_STAGEB + ((I) >> 1) * 2048 + 512 * (H)) : "memory")
-#ifndef E_LDS_SPREAD
-#define E_LDS_SPREAD 0   /* where a tile's 24 fragment reads sit.  0: MFMA gaps 0-7 of slot 1 carry three each (K, V lo, V hi).  1: slot 1 carries K in gaps
-                            0-7 and one V half in every gap.  2: one read per gap: K in slot 1 gaps 0-7, V halves in slot 1 gaps 8-15 and slot 2 gaps 0-7 */
-#endif
+// a tile's 24 fragment reads sit in MFMA gaps 0-7 of slot 1, three each (K, V lo, V hi); two other placements (one V half in every gap; one read per
+// gap over both slots) measured +1 ... +5 % and are gone (profiles/r03_attention_experiments.txt)
 
 // everything a block (query tile, head, clip) needs, wave-uniform
 struct EncBlk {
@@ -225,15 +214,9 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
     //      (cdna guide 5.7).  A wave-instruction fills 8 LDS rows of 128 B; lane (lrow, slot) writes slot `slot` of row r0 + lrow with
     //      SOURCE chunk slot ^ swz(row) (linear image, swizzle on the source address).  Wave w owns rows 16 w .. 16 w + 15 of every tile. ----
     auto dma16 = [&](const v4i_t& rsrc, int voff, int lds_addr) {
-#ifdef E_DMA_KEEP_M0
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-#else
         // M0 is written and consumed inside the one statement and not restored: nothing hipcc emits in this kernel reads M0 (gfx950 LDS
         // instructions do not need it; there is no compiler-issued LDS-DMA, s_sendmsg or v_movrel here -- checked in the .s)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-#endif
     };
     auto dma_tile = [&](const EncBlk& k, int t) {
         const int ks = __builtin_amdgcn_readfirstlane(lds_base + (t & (E_NST - 1)) * E_STAGEB + wave * 2048);
@@ -324,20 +307,10 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
         //  and with it the next MFMA -- behind every add's latency: 40 us of a 430-us launch)
         auto soft2 = [&](const int i, const f32x16 (&s)[2], u32x4 (&pk)[4], float (&psum)[4]) __attribute__((always_inline)) {
             const int ks = i >> 3, e = 2 * (i & 7);
-#if defined(E_TIMING_NOEXP)      /* TIMING EXPERIMENTS ONLY (wrong results) */
-            const float p0 = s[ks][e] * 0.5f, p1 = s[ks][e + 1] * 0.5f;
-#else
             const float p0 = __builtin_amdgcn_exp2f(s[ks][e]), p1 = __builtin_amdgcn_exp2f(s[ks][e + 1]);
-#endif
-#if !defined(E_TIMING_NOADD)
             psum[(2 * i) & 3] += p0;
             psum[(2 * i + 1) & 3] += p1;
-#endif
-#if defined(E_TIMING_NOCVT)
-            uint32_t w = __builtin_bit_cast(uint32_t, p0) ^ __builtin_bit_cast(uint32_t, p1);
-#else
             uint32_t w = e_cvt_pk(p0, p1);
-#endif
             asm volatile("" : "+v"(w));        // pinned here: the rare path overwrites P, and hipcc would sink the slot's 16 v_cvt_pk below its branch
             pk[ks * 2 + ((i & 7) >> 2)][i & 3] = w;
         };
@@ -446,16 +419,10 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 constexpr int PAR = IDX & 1, NXT = PAR ^ 1;
                 // tile t+1 must have landed before its K fragments are read in slot 1; tile t+2 (4 DMA instructions) may stay in flight
                 E_STAMP(0);                                    // 0: tile starts
-#ifdef E_TIMING_HALFSYNC   /* TIMING EXPERIMENT ONLY (races): what one DMA wait + barrier per TWO tiles would buy at most */
-                if (!(t & 1)) {
-#endif
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 E_STAMP(1);                                    // 1: tile t+1 landed (this wave's part)
                 E_BARRIER();
-#ifdef E_TIMING_HALFSYNC
-                }
-#endif
                 E_STAMP(2);                                    // 2: barrier passed
                 if (t + 3 < nt) dma_tile(cur, t + 3);          // stage (t+3)&3 = (t-1)&3: last read (V(t-1)) before the barrier above
                 E_FENCE();
@@ -466,15 +433,7 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                     (void)&sb; (void)&cb; (void)&pkb; (void)&kaddr; (void)&vaddr;
                     E_SLOT_MFMA(i, sb, PAR, A_QB, cb, A_OB, PAR, pkb);
                     soft2(i, sa, pka, ps4);
-#if E_LDS_SPREAD == 0
                     if constexpr (i < 8) { E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1)); E_READ_V(NXT, i, IDX); }
-#elif E_LDS_SPREAD == 1
-                    if constexpr (i < 8) E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1));
-                    E_READ_VH(NXT, i >> 1, i & 1, IDX);
-#else
-                    if constexpr (i < 8) E_READ_K(NXT, i, (IDX + 1) & (E_NST - 1));
-                    else E_READ_VH(NXT, (i - 8) >> 1, (i - 8) & 1, IDX);
-#endif
                     E_FENCE();
                 });
                 float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
@@ -489,14 +448,8 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
                 static_for<0, 16>([&](auto it) {
                     constexpr int i = decltype(it)::value;
                     (void)&sa; (void)&ca; (void)&pka;
-#if E_LDS_SPREAD == 2
-                    if constexpr (i == 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); E_FENCE(); }   // V(t) halves 8..15 are in their registers
-#endif
                     E_SLOT_MFMA(i, sa, NXT, A_QA, ca, A_OA, NXT, pka);
                     soft2(i, sb, pkb, ps4);
-#if E_LDS_SPREAD == 2
-                    if constexpr (i < 8) { (void)&vaddr; E_READ_VH(NXT, (i + 8) >> 1, (i + 8) & 1, IDX); }
-#endif
                     E_FENCE();
                 });
                 ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
@@ -611,12 +564,10 @@ __global__ __launch_bounds__(256, 1) void attn_enc64_kernel(EncAttnP p) {
 
 // Called by afhip_attention (attention.hip) for the shape this form covers; returns false when it does not apply.
 bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AFHIP_ATTN_ENC64"); on = (e && e[0] == '0') ? 0 : 1; }   // A/B switch
-    if (!on) return false;
+    if (!afhip_opt(AFHIP_OPT_ATTN_ENC64)) return false;   // A/B switch
     if (a->dtype != AFHIP_BF16 || a->hd != 64 || !a->q_prescaled || a->causal || a->key_split > 0 || a->n_q != a->n_kv || a->Tq != a->Tk) return false;
     if (a->new_k || a->seq_pos) return false;
-    if ((long long)a->Tk * a->ld_kv * 2 >= (1ll << 31)) return false;      // 32-bit DMA offsets inside one (clip, head)
+    if ((long long)a->Tk * a->ld_kv * 2 >= (1ll << 31) || (long long)a->Tq * a->ld_q * 2 >= (1ll << 31)) return false;      // 32-bit DMA offsets inside one (clip, head), K / V and Q
     EncAttnP p;
     p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->out;
     p.key_len = a->key_len; p.row_off = a->row_off;
@@ -639,7 +590,7 @@ bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s) {
     int ncu = afhip_cu_count();
     ncu = ncu >= 8 ? (ncu / 8) * 8 : ncu;
     int grid = nblk < ncu ? (int)nblk : ncu;
-    { const char* e = getenv("AFHIP_ENC64_ONE_BLOCK_PER_WG"); if (e && e[0] == '1') grid = (int)nblk; }   // A/B switch, read per call
+    if (afhip_opt(AFHIP_OPT_ENC64_ONE_BLOCK_PER_WG)) grid = (int)nblk;   // A/B switch
     hipLaunchKernelGGL(attn_enc64_kernel, dim3((unsigned)grid), dim3(256), E_LDS_TOTAL, s, p);
     return true;
 }

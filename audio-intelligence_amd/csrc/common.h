@@ -47,6 +47,16 @@ static inline size_t dtype_size(int dt) { return dt == AFHIP_BF16 ? 2 : 4; }
 
 // compute units of the current device (cached per process; 256 on MI355X)
 int afhip_cu_count();
+// ---- tuning / A-B switches.  Every switch is an entry of ONE table (api.hip): its default, overridden by the environment variable
+// AFHIP_<NAME> read ONCE when the library is loaded, or by afhip_set_option() (tests flip a switch inside one process with it).  Launch
+// paths read an int from the table: no getenv, no string compare.
+enum afhip_opt_id {
+    AFHIP_OPT_ATTN_NBUF, AFHIP_OPT_ATTN_LDS_PAD, AFHIP_OPT_ATTN_LAG, AFHIP_OPT_ATTN_ENC64, AFHIP_OPT_ENC64_ONE_BLOCK_PER_WG,
+    AFHIP_OPT_DECODE_CHAIN, AFHIP_OPT_DECODE_MERGE, AFHIP_OPT_DECODE_KEY_SPLIT, AFHIP_OPT_FP8_MASK, AFHIP_OPT_FP8_FC2,
+    AFHIP_OPT_GEMM_SMALL_TILE, AFHIP_OPT_GEMM_GROUP_M, AFHIP_OPT_GEMM_MFMA16, AFHIP_OPT_GEMM_PP,
+    AFHIP_OPT_SKINNY_ALDS, AFHIP_OPT_SKINNY_STREAM, AFHIP_OPT_SKINNY_PERSIST, AFHIP_OPT_LOGMEL_DFT, AFHIP_OPT_COUNT
+};
+int afhip_opt(int id);
 // packed (ragged) encoder batches, norm.hip (C++ linkage: internal to the library)
 int afhip_ragged_row_offsets(const int32_t* len, int32_t* row_off, int B, hipStream_t s);
 int afhip_ragged_pack_rows(const void* src, void* dst, const int32_t* row_off, const int32_t* len, int B, int T, int row_bytes, hipStream_t s);

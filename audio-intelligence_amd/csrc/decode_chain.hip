@@ -253,9 +253,7 @@ void fill(ImgDesc& p, const void* A, const void* W, const void* bias, const void
 
 // ---- host side (C++ linkage: called by llm.hip) ----------------------------------------------------------------------------
 int afhip_decode_chain_mode() {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("AFHIP_DECODE_CHAIN"); mode = e ? atoi(e) : 1; }   // 0 = off, 1 = one phase per launch (default), 2 = chained phases (read once per process)
-    return mode;
+    return afhip_opt(AFHIP_OPT_DECODE_CHAIN);   // 0 = off, 1 = one phase per launch (default), 2 = chained phases
 }
 
 bool afhip_decode_chain_supported(const afhip_llm_weights* w, int B) {

@@ -167,13 +167,7 @@ int encoder_forward_impl(const afhip_encoder_weights* w, const void* mel_btc, co
             // behind an explicit LayerNorm).  Default 6 = out + fc1: q / k / v stay bf16 because the softmax amplifies e4m3 noise on
             // its logits more than anything downstream -- measured through the LLM (tests/test_gpu_config5.py, 10 clips x 32 steps):
             // mask 7 (qkv too) 284-289 of 320 tokens equal to the bf16 run, mask 6 296, mask 14 (+ fc2) 294, mask 15 285
-            static int mask = -1;
-            if (mask < 0) {
-                const char* e = getenv("AFHIP_FP8_MASK");
-                mask = e ? atoi(e) : 6;
-                const char* e2 = getenv("AFHIP_FP8_FC2");
-                if (e2 && e2[0] == '1') mask |= 8;
-            }
+            const int mask = afhip_opt(AFHIP_OPT_FP8_MASK) | (afhip_opt(AFHIP_OPT_FP8_FC2) ? 8 : 0);
             // q | k | v in bf16: the LayerNorm-folded GEMM over the raw stream when the folded weights exist (row statistics from the
             // conv stem / the previous layer's bf16 fc2 epilogue, exactly as in the bf16 mode; q leaves prescaled for the encoder
             // attention kernel), else an explicit LayerNorm + the plain GEMM

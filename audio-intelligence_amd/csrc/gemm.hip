@@ -565,23 +565,18 @@ struct GemmProf {
 }  // namespace
 
 static bool force_small_tile() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AFHIP_GEMM_SMALL_TILE"); v = (e && e[0] == '1') ? 1 : 0; }   // A/B switch for benchmarking
-    return v == 1;
+    return afhip_opt(AFHIP_OPT_GEMM_SMALL_TILE) == 1;   // A/B switch for benchmarking
 }
 
 static int gemm_group_m() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AFHIP_GEMM_GROUP_M"); v = e ? atoi(e) : 4; if (v < 1) v = 1; }
-    return v;
+    const int v = afhip_opt(AFHIP_OPT_GEMM_GROUP_M);
+    return v < 1 ? 1 : v;
 }
 
 static bool use_mfma16() {
     // A/B switch: the 16x16x32 body measured within +-3 % of the 32x32x16 one on MI355X (tools/gemm_bench.py), so the
     // 32x32 body (shared with the f32 path) stays the default
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AFHIP_GEMM_MFMA16"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
+    return afhip_opt(AFHIP_OPT_GEMM_MFMA16) == 1;
 }
 
 // persistent ping-pong kernel for the large bf16 shapes (gemm_pp.hip)
@@ -627,6 +622,9 @@ extern "C" int afhip_gemm(const afhip_gemm_args* a, void* stream) {
     AFHIP_CHECK(a != nullptr, "afhip_gemm: null args");
     AFHIP_CHECK(a->dtype == AFHIP_F32 || a->dtype == AFHIP_BF16, "afhip_gemm: bad dtype %d", a->dtype);
     AFHIP_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "afhip_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    // the e4m3-output / one-scale-for-every-row forms belong to the e4m3-operand GEMM only: on bf16 operands they would be silently ignored
+    // and the consumer would read bf16 bytes as e4m3
+    AFHIP_CHECK(a->a_fp8 || (!a->out_fp8 && a->a_scale_const == 0.f), "afhip_gemm: out_fp8 / a_scale_const need a_fp8 (e4m3 operands)");
     if (a->a_fp8) {
         // e4m3 x e4m3 -> bf16 (BASELINE config 5): the persistent ping-pong kernel's F8 form is the one implementation
         AFHIP_CHECK(a->A && a->W && a->C && (a->a_scale || a->a_scale_const > 0.f) && a->w_scale, "afhip_gemm(fp8): null operand / scale");

@@ -39,12 +39,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#ifndef PP_SETPRIO
-#define PP_SETPRIO 1   /* s_setprio(1) around each MFMA cluster (keeps hipcc from moving MFMAs across the barriers, cdna guide T5) */
-#endif
 
 namespace {
 
+// The schedule below is the one that survived the round-2 / round-3 same-box A/Bs (profiles/r03_gemm_pp_sched_ab.txt): s_setprio(1) around
+// each MFMA cluster; a phase's half-tile DMA issued in its LOAD section AFTER the fragment reads, no blanket lgkmcnt(0) in front of the
+// MFMAs, fragment reads K-half-major; K half 0 of the next tile's A0 fragments read one phase early (8 / 4 / 8 / 4 fragment reads per LOAD
+// section).  Measured and removed: the DMA inside the MFMA section (5-7 % slower), one more phase of DMA lookahead (0-7 % slower), two
+// phases of 32 MFMAs per K tile (no gain), tile-major fragment reads.
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
 constexpr int PP_HALF = 16384;           // 128 rows x 128 B
 constexpr int PP_STAGE = 4 * PP_HALF;    // A0 A1 B0 B1
@@ -140,35 +142,11 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds_dst + 8192), 16, voff1, soff, 0, 0);
 }
 
-#ifndef PP_VARIANT
-#define PP_VARIANT 2   /* tuning switches (0 / 1 / 2 / 3 measured on qkv: 1187 / 1140 / 1207 / 1170 TF): bit 0 = issue the DMA before the fragment reads of a LOAD section; bit 1 = no blanket lgkmcnt(0) in front of the MFMAs; bit 2 = fragment reads tile-major instead of K-half-major */
-#endif
-#ifndef PP_DMA_IN_MFMA
-#define PP_DMA_IN_MFMA 0   /* 1: a phase's half-tile DMA is issued inside its MFMA section (measured 5-7 % SLOWER: the DMA issue stalls the wave's own MFMA stream); 0: in its LOAD section (8-phase template) */
-#endif
 // counted wait of the LOAD sections of phases 3, 0, 1: the half-tile read in the NEXT phase has landed, younger ones stay in flight.
 // DMA in the LOAD section: issued so far includes this phase's -> 4 half-tiles (8 instructions) younger; DMA in the MFMA section:
 // this phase's is not issued yet -> 3 half-tiles (6 instructions) younger.
-#if PP_DMA_IN_MFMA
-#define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-#else
 #define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#endif
 #define PP_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#ifndef PP_SCHED
-#define PP_SCHED 2   /* schedule of the 8 half-tile slots; round-3 same-box A/B at M = 48000 in profiles/r03_gemm_pp_sched_ab.txt.
-                        0: one half-tile DMA per phase (B1, A1 of tile t+1, A0, B0 of tile t+2); fragment reads per LOAD section 12 / 4 / 8 / 0.
-                        1: DMAs A1(t+1) | - | A0 B0 (t+2) | B1(t+2): every slot refilled exactly 2 phases after its read, 5 phases (80 KiB) of
-                           DMA lookahead instead of 4.  0-7 % SLOWER (fc2 0.502 -> 0.540 ms): the kernel is not short of lookahead, and the
-                           two-DMA LOAD section of phase 2 outlasts the partner's MFMA section.
-                        2: schedule 0 with K half 0 of the next tile's A0 fragments read in phase 3 (A0 is the one half-tile with a spare
-                           phase of DMA slack, so its landing wait moves to phase 2): reads 8 / 4 / 8 / 4.  +1.5-3 % on qkv / out / fc1+gelu,
-                           fc1 plain and fc2 unchanged; bf16 only (the e4m3 form reads both K halves as one operand and keeps 0)
-                        3: TWO phases of 32 MFMAs per K tile (A0 x all columns, A1 x all columns), LOAD sections closed by lgkmcnt(0) so a slot
-                           is refilled the phase after its read: half the barriers of 0 / 2, same DMA lookahead.  Correct (same tests) and
-                           NOT faster: qkv +-3 % run to run, fc2 0.515 -> 0.528 ms, headline step 71.6 -> 72.1 ms on one box.  With the card at
-                           its 1400 W cap (profiles/r03_clock_power_probe.txt) a denser matrix stream is paid back in clock */
-#endif
 #define PP_WAIT_VM10() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
 #define PP_BARRIER()                              \
     do {                                          \
@@ -243,12 +221,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    bf16x8 fa0k0[4];                        // PP_SCHED 2: K half 0 of the NEXT tile's A0 fragments, read one phase early
+    bf16x8 fa0k0[4];                        // K half 0 of the NEXT tile's A0 fragments, read one phase early
     // ... except in the two forms whose epilogue (bias + residual + row statistics, or + GELU) already needs all 256 registers: the 16
     // fragment registers that then stay live across it spill 7-24 VGPRs, and fc2 (the statistics form) gained nothing from the schedule
-    constexpr bool EARLY_A0 = PP_SCHED == 2 && !F8 && !(HAS_BIAS && HAS_RES && (STATS || ACT == AFHIP_ACT_GELU));
-    // PP_SCHED 3: TWO phases of 32 MFMAs per K tile instead of four of 16 -- half the barriers (bf16 form only)
-    constexpr bool TWO_PHASE = PP_SCHED == 3 && !F8;
+    constexpr bool EARLY_A0 = !F8 && !(HAS_BIAS && HAS_RES && (STATS || ACT == AFHIP_ACT_GELU));
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef int v8i_t __attribute__((ext_vector_type(8)));
     const int unit_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte: block scales off
@@ -264,38 +240,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     pp_cur_advance(p, c1, n_my);                  // stream tile 1
     pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[0][0], voffA[0][1], dma_dst + PP_STAGE + PP_OFF_A0);
     pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[0][0], voffB[0][1], dma_dst + PP_STAGE + PP_OFF_B0);
-#if PP_SCHED == 1
-    pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_STAGE + PP_OFF_B1);
-#endif
-    if constexpr (TWO_PHASE) pp_dma_half(c1.wbase, c1.wnrec, c1.koff, voffB[1][0], voffB[1][1], dma_dst + PP_STAGE + PP_OFF_B1);
     c2 = c1;
     pp_cur_advance(p, c2, n_my);                  // stream tile 2
-#if PP_SCHED == 1
-    PP_WAIT_VM10();                               // A0(0), B0(0) of this wave have landed (5 half-tiles younger)
-#else
     PP_WAIT_VM8();                                // A0(0), B0(0) of this wave have landed
-#endif
     PP_BARRIER();
-#if PP_SCHED == 2
     if constexpr (EARLY_A0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + PP_OFF_A0 + aoff0 + i * 2048);
     }
-#endif
     if (grp == 1) PP_BARRIER();                   // stagger: group 1 runs one barrier behind group 0
 
-    // 16 MFMAs of one quadrant; with PP_DMA_IN_MFMA the phase's LDS-DMA half-tile is issued between the two K halves, in the
+    // 16 MFMAs of one quadrant (with the DMA-in-MFMA variant, now removed, the phase's LDS-DMA half-tile was issued between the two K halves, in the
     // issue slots the wave's own MFMAs leave free (an MFMA holds the port 8 of its 16 cycles), instead of lengthening the LOAD
-    // section its partner's matrix pipe waits on
+    // section its partner's matrix pipe waits on: 5-7 % slower)
     auto mfma_quad = [&](auto ha_tag, auto hb_tag, bf16x8 (&fbx)[2][2], auto&& dma) {
         constexpr int HA = decltype(ha_tag)::value, HB = decltype(hb_tag)::value;
-#if !(PP_VARIANT & 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if PP_SETPRIO
         __builtin_amdgcn_s_setprio(1);
-#endif
         if constexpr (F8) {
             v8i_t (&fb8)[2] = (HB == 0) ? fb0_8 : fb1_8;
 #pragma unroll
@@ -316,17 +276,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kk], (EARLY_A0 && HA == 0 && kk == 0) ? fa0k0[i] : fa[i][kk], acc[HA][i][HB][j], 0, 0, 0);
-#if PP_DMA_IN_MFMA
-            if (kk == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                dma();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
         }
-#if PP_SETPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // fragment reads in the order the MFMAs consume them (K half 0 of every tile, then K half 1): with per-fragment lgkmcnt waits
     // the first MFMAs start while the second half is still in flight
@@ -339,18 +290,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             }
             return;
         }
-#if PP_VARIANT & 4
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i][0] = *reinterpret_cast<const bf16x8*>(half + aoff0 + i * 2048);
-            fa[i][1] = *reinterpret_cast<const bf16x8*>(half + aoff1 + i * 2048);
-        }
-#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i][0] = *reinterpret_cast<const bf16x8*>(half + aoff0 + i * 2048);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(half + aoff1 + i * 2048);
-#endif
     };
     auto read_b = [&](const char* half, bf16x8 (&fbx)[2][2]) {
         if constexpr (F8) {
@@ -362,18 +305,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             }
             return;
         }
-#if PP_VARIANT & 4
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fbx[j][0] = *reinterpret_cast<const bf16x8*>(half + boff0 + j * 2048);
-            fbx[j][1] = *reinterpret_cast<const bf16x8*>(half + boff1 + j * 2048);
-        }
-#else
 #pragma unroll
         for (int j = 0; j < 2; ++j) fbx[j][0] = *reinterpret_cast<const bf16x8*>(half + boff0 + j * 2048);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fbx[j][1] = *reinterpret_cast<const bf16x8*>(half + boff1 + j * 2048);
-#endif
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -388,92 +323,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         auto dma1 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
         auto dma2 = [&]() { pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0); };
         auto dma3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0); };
-        if constexpr (TWO_PHASE) {
-            // phase 0: A rows 0-127 (A0) x all 256 columns; phase 1: A rows 128-255 (A1).  Every LOAD section ends with lgkmcnt(0) in front of
-            // its barrier, so a slot is free for refill as soon as both groups have passed the barrier after reading it: A1 of the other
-            // stage (read in phase 1 of the previous K tile) is refilled in phase 0, A0 B0 B1 of this stage (read in phase 0) in phase 1.
-            // Stream order ... A1(t+1) | A0 B0 B1 (t+2) | A1(t+2) | ...: every counted wait leaves 4 half-tiles (8 instructions) in flight.
-            auto mfma_half = [&](auto ha_tag) {
-                constexpr int HA = decltype(ha_tag)::value;
-#if PP_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[HA][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][kk], fa[i][kk], acc[HA][i][0][j], 0, 0, 0);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[HA][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][kk], fa[i][kk], acc[HA][i][1][j], 0, 0, 0);
-                    }
-#if PP_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            };
-            // phase 0
-            read_b(st + PP_OFF_B0, fb0);
-            read_b(st + PP_OFF_B1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(st + PP_OFF_A0);
-            pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1);
-            PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 (t+1), A1(t+1) in flight
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            mfma_half(I0{});
-            PP_BARRIER();
-            // phase 1
-            read_a(st + PP_OFF_A1);
-            pp_dma_half(c2.abase, c2.anrec, c2.koff, voffA[0][0], voffA[0][1], d_same + PP_OFF_A0);
-            pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[0][0], voffB[0][1], d_same + PP_OFF_B0);
-            pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[1][0], voffB[1][1], d_same + PP_OFF_B1);
-            PP_WAIT_VM8();                            // A0 B0 B1 (t+1) landed; A1(t+1), A0 B0 B1 (t+2) in flight
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            mfma_half(I1{});
-            PP_BARRIER();
-        } else {
-#if PP_SCHED == 1
-        // issue order of a K tile: A1(t+1) | - | A0(t+2) B0(t+2) | B1(t+2); in the stream that is the natural order A0 B0 B1 A1 of
-        // every tile, so each counted wait below leaves exactly the younger half-tiles (2 instructions each) in flight
-        auto x0 = [&]() { pp_dma_half(c1.abase, c1.anrec, c1.koff, voffA[1][0], voffA[1][1], d_other + PP_OFF_A1); };
-        auto x3 = [&]() { pp_dma_half(c2.wbase, c2.wnrec, c2.koff, voffB[1][0], voffB[1][1], d_same + PP_OFF_B1); };
-        auto nodma = [&]() {};
-        // phase 0: reads A0 B0 (t); refills A1 of the other stage (read in phase 2 of tile t-1)
-        read_b(st + PP_OFF_B0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(st + PP_OFF_A0);
-        x0();
-        PP_WAIT_VM10();                           // B1(t) landed; A1(t) A0 B0 B1 (t+1) A1(t+1) in flight
-        PP_BARRIER();
-        mfma_quad(I0{}, I0{}, fb0, nodma);
-        PP_BARRIER();
-        // phase 1: reads B1 (t)
-        read_b(st + PP_OFF_B1, fb1);
-        PP_WAIT_VM8();                            // A1(t) landed; A0 B0 B1 A1 (t+1) in flight
-        PP_BARRIER();
-        mfma_quad(I0{}, I1{}, fb1, nodma);
-        PP_BARRIER();
-        // phase 2: reads A1 (t); refills A0 and B0 of this stage (read in phase 0)
-        read_a(st + PP_OFF_A1);
-        dma2();
-        dma3();
-        PP_BARRIER();
-        mfma_quad(I1{}, I1{}, fb1, nodma);
-        PP_BARRIER();
-        // phase 3: refills B1 of this stage (read in phase 1)
-        x3();
-        PP_WAIT_VM10();                           // A0 B0 (t+1) landed; B1 A1 (t+1) A0 B0 B1 (t+2) in flight
-        PP_BARRIER();
-        mfma_quad(I1{}, I0{}, fb0, nodma);
-        PP_BARRIER();
-#else
+        {
         // phase 0
-#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
-        dma0();
-#endif
         read_b(st + PP_OFF_B0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (EARLY_A0) {     // K half 0 of these fragments was read in phase 3 of the previous K tile
@@ -482,9 +333,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         } else {
             read_a(st + PP_OFF_A0);
         }
-#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma0();
-#endif
         PP_WAIT_VM();
         PP_STAMP();
         PP_BARRIER();
@@ -494,13 +343,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_BARRIER();
         PP_STAMP();
         // phase 1
-#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
-        dma1();
-#endif
         read_b(st + PP_OFF_B1, fb1);
-#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma1();
-#endif
         PP_WAIT_VM();
         PP_STAMP();
         PP_BARRIER();
@@ -510,13 +354,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_BARRIER();
         PP_STAMP();
         // phase 2
-#if !PP_DMA_IN_MFMA && (PP_VARIANT & 1)
-        dma2();
-#endif
         read_a(st + PP_OFF_A1);
-#if !PP_DMA_IN_MFMA && !(PP_VARIANT & 1)
         dma2();
-#endif
         if constexpr (EARLY_A0) PP_WAIT_VM8();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
         PP_STAMP();
         PP_BARRIER();
@@ -530,9 +369,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + (S ^ 1) * PP_STAGE + PP_OFF_A0 + aoff0 + i * 2048);
         }
-#if !PP_DMA_IN_MFMA
         dma3();
-#endif
         PP_WAIT_VM();
         PP_STAMP();
         PP_BARRIER();
@@ -541,7 +378,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
-#endif
         }
         c1 = c2;
         pp_cur_advance(p, c2, n_my);
@@ -749,8 +585,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
 }
 
 bool pp_enabled() {
-    const char* e = getenv("AFHIP_GEMM_PP");   // A/B switch for benchmarking (read per call so one process can compare)
-    return !(e && e[0] == '0');
+    return afhip_opt(AFHIP_OPT_GEMM_PP) != 0;   // A/B switch for benchmarking (afhip_set_option flips it inside one process)
 }
 
 int pp_num_cus() {

@@ -463,11 +463,10 @@ void launch_mode(const SkinnyP& p, int amode, hipStream_t s) {
     const size_t lds = ((size_t)NW * NT * MT * 256 + NW * MT * 16) * sizeof(float);
     if constexpr (sizeof(T) == 2 && MT == 1) {
         const size_t img = (size_t)p.a_rows * p.K * 2;
-        static int use = -1;
         // A/B switch, default OFF for bf16 weights: measured 3.81-3.93 vs 3.63 ms per 7B decode step (the 57-KiB image halves the
         // workgroups per CU of gate/up, and co-resident workgroups hiding each other's ramp matter more than the saved loads);
         // the e4m3 kernel, whose K step carries 8 activation / gain loads per 2 NT weight loads, gains 3.5 % and keeps it on
-        if (use < 0) { const char* e = getenv("AFHIP_SKINNY_ALDS"); use = (e && e[0] == '1') ? 1 : 0; }
+        const int use = afhip_opt(AFHIP_OPT_SKINNY_ALDS) == 1;
         if (use && amode != A_SWIGLU && p.K % 64 == 0 && lds + img <= SKINNY_ALDS_MAX) {
             static unsigned long long attr_done = 0;
             if (afhip_first_use_on_device(&attr_done)) {
@@ -566,9 +565,8 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     p.n_tiles = 1; p.am_iv = nullptr; p.am_n_iv = 0; p.am_val = nullptr; p.am_idx = nullptr;
     if (a->dtype == AFHIP_BF16 && mt == 1) {
         // the 7B decode step's form: one persistent workgroup per CU, the A operand through LDS only (gemm_stream.hip).
-        // AFHIP_SKINNY_STREAM=0 keeps the round-3 kernels (A/B switch, read per call so one process can compare the forms bit for bit)
-        const char* se = getenv("AFHIP_SKINNY_STREAM");
-        if (!(se && se[0] == '0')) {
+        // AFHIP_SKINNY_STREAM=0 keeps the round-3 kernels (A/B switch; afhip_set_option lets one process compare the forms bit for bit)
+        if (afhip_opt(AFHIP_OPT_SKINNY_STREAM) != 0) {
             SkinnyP ps = p;
             ps.n_tiles = sw_out ? 2 : (wide ? (p.a_rows == 8 ? 4 : 2) : nt_narrow);
             if (afhip_gemm_stream_bf16(ps, amode, s)) { AFHIP_LAUNCH_CHECK(); return 0; }
@@ -576,8 +574,7 @@ extern "C" int afhip_gemm_skinny(const afhip_gemm_args* a, void* stream) {
     }
     if (a->dtype == AFHIP_BF16 && sw_out && mt == 1 && amode != A_SWIGLU && a->K % 512 == 0) {
         // decode gate/up: the persistent pair form (one continuous weight stream per CU); AFHIP_SKINNY_PERSIST=0 keeps the plain form
-        const char* pe = getenv("AFHIP_SKINNY_PERSIST");      // A/B switch, read per call so one process can compare the two forms
-        const int persist = (pe && pe[0] == '0') ? 0 : 1;
+        const int persist = afhip_opt(AFHIP_OPT_SKINNY_PERSIST) != 0;      // A/B switch (afhip_set_option flips it inside one process)
         const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
         if (persist && lds <= 150 * 1024) {
             constexpr int PD = 4;      // K steps in flight per wave; 6 and 8 measured the same (3.47-3.52 ms per 7B step): not the limiter

@@ -437,8 +437,7 @@ void launch_mode8(const SkinnyF8P& p, int amode, hipStream_t s) {
     const size_t lds = ((size_t)8 * NT * MT * 256 + 8 * MT * 16) * sizeof(float);
     if constexpr (MT == 1) {
         const size_t img = (size_t)p.a_rows * p.K * 2;
-        static int use = -1;
-        if (use < 0) { const char* e = getenv("AFHIP_SKINNY_ALDS"); use = (e && e[0] == '0') ? 0 : 1; }     // A/B switch
+        const int use = afhip_opt(AFHIP_OPT_SKINNY_ALDS) != 0;     // A/B switch (default on for e4m3 weights)
         if (use && lds + img <= 120 * 1024) {
             static unsigned long long attr_done = 0;
             if (afhip_first_use_on_device(&attr_done)) {
@@ -505,8 +504,7 @@ int afhip_gemm_skinny_fp8_impl(const afhip_gemm_args* a, void* stream) {
     }
     if (sw_out && mt == 1 && a->K >= 1024) {
         // decode gate/up: persistent pair form (gemm_skinny.hip); AFHIP_SKINNY_PERSIST=0 keeps the plain form
-        const char* pe = getenv("AFHIP_SKINNY_PERSIST");      // A/B switch, read per call so one process can compare the two forms
-        const int persist = (pe && pe[0] == '0') ? 0 : 1;
+        const int persist = afhip_opt(AFHIP_OPT_SKINNY_PERSIST) != 0;      // A/B switch (afhip_set_option flips it inside one process)
         const size_t lds = (size_t)(2 * 8 * 2 * 256 + 16) * sizeof(float) + (size_t)p.a_rows * a->K * 2;
         if (persist && lds <= 150 * 1024) {
             constexpr int PD = 4;

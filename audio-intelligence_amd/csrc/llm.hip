@@ -9,29 +9,16 @@ namespace {
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 // merge of the decode attention's key-range partials: by the last-arriving workgroup inside the attention launch (1) or by a second
-// launch (0).  AFHIP_DECODE_MERGE overrides at run time (A/B).
-#ifndef DECODE_IN_LAUNCH_MERGE_DEFAULT
-#define DECODE_IN_LAUNCH_MERGE_DEFAULT 0
-#endif
-static int decode_in_launch_merge() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AFHIP_DECODE_MERGE"); v = e ? (e[0] == '1') : DECODE_IN_LAUNCH_MERGE_DEFAULT; }
-    return v;
-}
-#define DECODE_IN_LAUNCH_MERGE decode_in_launch_merge()
+// launch (0, the default: the in-launch form measured slower).  Option DECODE_MERGE (common.h) selects it.
+#define DECODE_IN_LAUNCH_MERGE (afhip_opt(AFHIP_OPT_DECODE_MERGE) == 1)
 #ifndef DECODE_KEY_SPLIT
 #define DECODE_KEY_SPLIT 128   /* keys per workgroup of the split-context decode attention (multiple of 64); 256 / 128 / 64 measured 3.85 / 3.79 / 3.84 ms per 7B step */
 #endif
 
-// experiment switch: AFHIP_DECODE_KEY_SPLIT = keys per workgroup at run time (a multiple of DECODE_KEY_SPLIT, which sized the workspace)
+// option DECODE_KEY_SPLIT = keys per workgroup at run time (a multiple of DECODE_KEY_SPLIT, which sized the workspace)
 static int decode_key_split() {
-    static int ks = 0;
-    if (ks == 0) {
-        const char* e = getenv("AFHIP_DECODE_KEY_SPLIT");
-        const int v = e ? atoi(e) : 0;
-        ks = (v >= DECODE_KEY_SPLIT && v % DECODE_KEY_SPLIT == 0) ? v : DECODE_KEY_SPLIT;
-    }
-    return ks;
+    const int v = afhip_opt(AFHIP_OPT_DECODE_KEY_SPLIT);
+    return (v >= DECODE_KEY_SPLIT && v % DECODE_KEY_SPLIT == 0) ? v : DECODE_KEY_SPLIT;
 }
 
 struct LlmWs {

@@ -639,9 +639,7 @@ extern "C" size_t afhip_log_mel_workspace_bytes(int B) {
 namespace {
 template <typename TO, int LAYOUT>
 void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* out, const float* tables, int* clipmax, hipStream_t s) {
-    static int use_dft = -1;
-    if (use_dft < 0) { const char* e = getenv("AFHIP_LOGMEL_DFT"); use_dft = (e && e[0] == '1') ? 1 : 0; }   // A/B switch: the folded-DFT MFMA form
-    if (use_dft) {
+    if (afhip_opt(AFHIP_OPT_LOGMEL_DFT) == 1) {   // A/B switch: the folded-DFT MFMA form
         const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FT * (NMEL + 1) : 0));
         static unsigned long long attr_done = 0;
         if (afhip_first_use_on_device(&attr_done))
@@ -650,8 +648,12 @@ void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* o
                            tables, out, clipmax);
     } else {
         const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FFT_FT * (NMEL + 1) : 0));
-        const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");   // diagnostic: 8 x s_memtime stamps of one workgroup
+#ifdef AFHIP_LOGMEL_STAMPS   /* diagnostic build only (tools/mel_stamps.py): 8 x s_memtime stamps of one workgroup */
+        const char* dp = getenv("AFHIP_LOGMEL_DBGPTR");
         unsigned long long* dbg = dp ? (unsigned long long*)strtoull(dp, nullptr, 0) : nullptr;
+#else
+        unsigned long long* dbg = nullptr;
+#endif
         // persistent over frame tiles: LM_WG_PER_CU workgroups per CU in one generation, each walking ceil(94 / gx) tiles
         int gx = cdiv(256 * LM_WG_PER_CU, B);
         gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);

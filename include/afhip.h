@@ -37,6 +37,10 @@ extern "C" {
 #define AFHIP_ACT_SWIGLU 2 /* silu(gate)*up on 32-row interleaved gate/up weights (modeling_qwen2.py:46-48) */
 
 int afhip_version(void);
+/* Tuning / A-B switches of the library live in one table (csrc/api.hip; names = the AFHIP_<NAME> environment variables, which are read
+ * ONCE when the library is loaded).  This sets one by name afterwards -- the tests compare two forms of a kernel inside one process
+ * with it.  Not a production control; returns an error for an unknown name. */
+int afhip_set_option(const char* name, int value);
 const char* afhip_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

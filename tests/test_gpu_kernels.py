@@ -34,6 +34,12 @@ def _tol(dt, f32_tol, bf16_tol):
     return f32_tol if dt == torch.float32 else bf16_tol
 
 
+def _opt(name, value):
+    """flip one switch of the library's option table (include/afhip.h: afhip_set_option) inside this process"""
+    from audio_intelligence_amd import _lib as L
+    L.check(L.lib().afhip_set_option(name.encode(), int(value)))
+
+
 def _check(got, ref, atol, rtol, what):
     got = got.float().cpu()
     err = (got - ref).abs()
@@ -476,11 +482,11 @@ def test_gemm_pingpong_persistent_path():
                         ref = ref + rf
                     c = ops.gemm(ad, wd, bias=bd if hb else None, act=act, residual=rd if hr else None)
                     _check(c, ref, *tol, f"pp gemm {M}x{N}x{K} act={act} bias={hb} res={hr}")
-        os.environ["AFHIP_GEMM_PP"] = "0"
+        _opt("GEMM_PP", 0)
         try:
             c_old = ops.gemm(ad, wd, bias=bd, act=L.ACT_GELU, residual=rd)
         finally:
-            os.environ.pop("AFHIP_GEMM_PP", None)
+            _opt("GEMM_PP", 1)
         c_new = ops.gemm(ad, wd, bias=bd, act=L.ACT_GELU, residual=rd)
         assert float((c_new.float() - c_old.float()).abs().max()) <= 0.07, "ping-pong vs one-barrier kernel"   # <= 1 bf16 ulp at |x| <= 8
     # in-place residual (out-proj / fc2 of the encoder: h += x @ W^T)
@@ -689,14 +695,14 @@ def test_gemm_skinny_swiglu_persistent_form_keeps_the_plain_forms_bits(fp8, M, H
         g.W = wdev.data_ptr()
     outs = []
     for persist in ("1", "0"):
-        os.environ["AFHIP_SKINNY_PERSIST"] = persist
+        _opt("SKINNY_PERSIST", persist)
         out = torch.full((M, I), float("nan"), dtype=dt, device=_dev())
         g.A, g.C = xd.data_ptr(), out.data_ptr()
         g.M, g.N, g.K, g.lda, g.ldw, g.ldc = M, 2 * I, H, H, H, I
         g.dtype, g.act, g.a_norm_w, g.a_norm_eps = L.dtype_code(dt), L.ACT_SWIGLU, gd.data_ptr(), 1e-6
         L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
         outs.append(out.cpu())
-    os.environ.pop("AFHIP_SKINNY_PERSIST")
+    _opt("SKINNY_PERSIST", 1)
     assert torch.equal(outs[0], outs[1]), "persistent and plain forms differ"
     var = xf.pow(2).mean(-1, keepdim=True)
     h = (gf * (xf * torch.rsqrt(var + 1e-6))).to(dt).float() if fp8 else gf * (xf * torch.rsqrt(var + 1e-6))
@@ -731,7 +737,7 @@ def test_gemm_stream_persistent_decode_form(case):
     rd, rf = _q(_rand(M, N, seed=105), dt)
     outs = []
     for stream in ("1", "0"):
-        os.environ["AFHIP_SKINNY_STREAM"] = stream
+        _opt("SKINNY_STREAM", stream)
         out = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else dt, device=_dev())
         g = L.GemmArgs()
         g.A, g.W, g.C = xd.data_ptr(), wd.data_ptr(), out.data_ptr()
@@ -745,7 +751,7 @@ def test_gemm_stream_persistent_decode_form(case):
             g.residual, g.ldres = rd.data_ptr(), N
         L.check(lib.afhip_gemm_skinny(C.byref(g), L.stream_ptr()))
         outs.append(out.float().cpu())
-    os.environ.pop("AFHIP_SKINNY_STREAM")
+    _opt("SKINNY_STREAM", 1)
     h = xf
     if rms:
         h = gf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
@@ -868,10 +874,12 @@ def test_attention_prescaled_small_and_ragged_shapes(T):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,lens", [(1500, None), (1500, [1500, 777, 64]), (700, [700, 1, 65]), (257, [257, 130, 2])])
-def test_attention_encoder_two_forms_bit_identical(T, lens, monkeypatch):
-    """attention_enc8.hip (8 waves x 32 queries, two waves per SIMD half a tile apart; opt-in, AFHIP_ATTN_ENC8=1) and attention_enc.hip
-    (4 waves x 64 queries, the default) run the same MFMA sequence per accumulator, the same four partial row sums and the same lag rule:
-    their outputs must be equal BIT FOR BIT -- full clips, ragged key lengths with a spike that raises the lag, and packed rows."""
+def test_attention_encoder_three_forms_agree(T, lens):
+    """The encoder attention has three forms for bf16 / head_dim 64 / prescaled q: the one-wave-per-SIMD kernel (attention_enc.hip, the
+    default), the generic kernel with the lagged maximum (attn_kernel<bf16, 64, 2, LAG>: what runs when the first declines a shape, option
+    ATTN_ENC64 = 0) and the generic kernel with the plain running maximum (ATTN_LAG = 0).  ADVICE round 3: the second was reached by no test.
+    All three on the same inputs -- full clips, ragged key lengths with a spike that raises the lag, packed rows -- must agree to bf16
+    rounding of the output and with the f64 softmax."""
     from audio_intelligence_amd import ops
     B, H = 3, 20
     g = torch.Generator().manual_seed(T + (len(lens) if lens else 0))
@@ -881,25 +889,37 @@ def test_attention_encoder_two_forms_bit_identical(T, lens, monkeypatch):
     qkv = qkv.to(torch.bfloat16).to(_dev())
     kl = torch.tensor(lens, dtype=torch.int32, device=_dev()) if lens else None
 
-    def both(fn):
-        monkeypatch.setenv("AFHIP_ATTN_ENC8", "1")
-        a = fn()
-        monkeypatch.setenv("AFHIP_ATTN_ENC8", "0")
-        b = fn()
-        torch.cuda.synchronize()
-        return a, b
+    def forms(fn):
+        outs = []
+        try:
+            for enc64, lag in ((1, 1), (0, 1), (0, 0)):
+                _opt("ATTN_ENC64", enc64)
+                _opt("ATTN_LAG", lag)
+                outs.append(fn().float().cpu())
+        finally:
+            _opt("ATTN_ENC64", 1)
+            _opt("ATTN_LAG", 1)
+        return outs
 
-    a, b = both(lambda: ops.attention_packed(qkv, H, key_len=kl, q_prescaled=True))
+    outs = forms(lambda: ops.attention_packed(qkv, H, key_len=kl, q_prescaled=True))
+    if lens:
+        for o in outs:
+            for i, n in enumerate(lens):
+                o[i, n:] = 0
+    q, k, v = (qkv[..., i * H * 64:(i + 1) * H * 64].float().cpu().reshape(B, T, H, 64) for i in range(3))
+    ref = _ref_attention_exp2(q, k, v, torch.tensor(lens) if lens else None)
     if lens:
         for i, n in enumerate(lens):
-            a[i, n:] = 0
-            b[i, n:] = 0
-    assert bool(torch.isfinite(a.float()).all())
-    assert torch.equal(a, b)
+            ref[i, n:] = 0
+    lim = 2e-2 + 2e-2 * float(ref.abs().max())
+    for name, o in zip(("enc64", "generic lagged", "generic plain"), outs):
+        assert bool(torch.isfinite(o).all()), name
+        assert float((o - ref).abs().max()) <= lim, (name, float((o - ref).abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= lim and float((outs[1] - outs[2]).abs().max()) <= lim
     if lens:
         rows = torch.cat([qkv[i, :n] for i, n in enumerate(lens)], 0).contiguous()
-        a, b = both(lambda: ops.attention_ragged(rows, H, torch.tensor(lens, dtype=torch.int32), max(lens), q_prescaled=True))
-        assert torch.equal(a, b)
+        po = forms(lambda: ops.attention_ragged(rows, H, torch.tensor(lens, dtype=torch.int32), max(lens), q_prescaled=True))
+        assert float((po[0] - po[1]).abs().max()) <= lim and float((po[1] - po[2]).abs().max()) <= lim
 
 
 def test_attention_encoder_e4m3_output():

@@ -5,8 +5,7 @@ import glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "audio-intelligence_amd", "csrc")
 extra = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "logmel.hip": ["-fno-slp-vectorize"],
-         "attention_enc.hip": ["-Wno-inline-asm", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize"],
-         "attention_enc8.hip": ["-Wno-inline-asm", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize"]}
+         "attention_enc.hip": ["-Wno-inline-asm", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize"]}
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 bad = 0
 for f in files:
