@@ -57,6 +57,9 @@ enum afhip_opt_id {
     AFHIP_OPT_SKINNY_ALDS, AFHIP_OPT_SKINNY_STREAM, AFHIP_OPT_SKINNY_PERSIST, AFHIP_OPT_LOGMEL_DFT, AFHIP_OPT_COUNT
 };
 int afhip_opt(int id);
+// measurement hook of bench.py (afhip_prof_enable / afhip_prof_collect, gemm.hip): HIP events around one launch on its stream
+int afhip_prof_begin(hipStream_t s);
+void afhip_prof_end(int slot, hipStream_t s, double flops, int tag);
 // packed (ragged) encoder batches, norm.hip (C++ linkage: internal to the library)
 int afhip_ragged_row_offsets(const int32_t* len, int32_t* row_off, int B, hipStream_t s);
 int afhip_ragged_pack_rows(const void* src, void* dst, const int32_t* row_off, const int32_t* len, int B, int T, int row_bytes, hipStream_t s);

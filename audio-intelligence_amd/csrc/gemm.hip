@@ -601,6 +601,21 @@ extern "C" int afhip_prof_enable(int max_launches) {
 }
 
 // Waits for the recorded events; returns launches / summed milliseconds / summed algorithmic FLOPs (2MNK) of
+// Recording hooks for launches outside this file (attention.hip): begin returns the slot or -1 when recording is off / full.
+int afhip_prof_begin(hipStream_t s) {
+    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    const int slot = g_prof.n;
+    (void)hipEventRecord(g_prof.ev[2 * slot], s);
+    return slot;
+}
+void afhip_prof_end(int slot, hipStream_t s, double flops, int tag) {
+    if (slot < 0) return;
+    (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+    g_prof.flops[slot] = flops;
+    g_prof.dtype[slot] = tag;
+    g_prof.n = slot + 1;
+}
+
 // the afhip_gemm launches of `dtype` since afhip_prof_enable, and switches recording off.
 extern "C" int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops) {
     AFHIP_CHECK(n_launches && total_ms && total_flops, "afhip_prof_collect: null pointer");

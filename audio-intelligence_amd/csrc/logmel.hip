@@ -10,7 +10,7 @@
 //     i.e. two [64 x 208] . [208 x 224] products in exact f32 on v_mfma_f32_32x32x2_f32; the folded operand
 //     is built in registers from LDS, the cos / sin tables ([bin][n], 8 consecutive n per lane) stream from L2;
 //   * power -> LDS -> banded mel filter bank (394 non-zeros) -> log10 -> (x + 4) / 4 written ONCE, in the caller's layout and
-//     dtype, + per-clip running max of the log10 values (ordered-int atomicMax).
+//     dtype, + the (max, min) of the log10 values each workgroup wrote (no atomics, no init launch).
 // Floor fix-up (in place): out = max(out, ((clipmax - 8) + 4) / 4).  Rounding is monotone, so this equals the reference's
 //     (max(x, clipmax - 8) + 4) / 4 bit for bit in f32 and in bf16; the f32 [B,3000,128] intermediate of the old two-pass form
 //     (49 MB written + 49 MB read per 32 clips) is gone: HBM traffic = wav read + mel write + one read of the mel.
@@ -69,7 +69,7 @@ constexpr int KCMAX = 12;
 // floats follow the tile -- adds exactly +0, so the sum keeps the reference's left-to-right order and its bits.
 template <int NFR, int PITCH, typename TO, int LAYOUT, int PAD>
 __device__ __forceinline__ float mel_tail_half(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
-                                               TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int m, int w) {
+                                               TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int m, int w, float& mn) {
     const int k0 = cband[3 * m], kc = cband[3 * m + 1], wo = cband[3 * m + 2];
     float wk[PAD];
 #pragma unroll
@@ -92,6 +92,7 @@ __device__ __forceinline__ float mel_tail_half(const float* __restrict__ pw, con
             if constexpr (LAYOUT == 1) out[((long long)b * NFRAMES + t) * NMEL + m] = from_f32<TO>(y);
             else tr[f * (NMEL + 1) + m] = y;
             mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
         }
     }
     return mx;
@@ -99,7 +100,7 @@ __device__ __forceinline__ float mel_tail_half(const float* __restrict__ pw, con
 
 template <int NFR, int PITCH, typename TO, int LAYOUT>
 __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const float* __restrict__ cw, const int* __restrict__ cband,
-                                          TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int tid) {
+                                          TO* __restrict__ out, float* __restrict__ tr, int b, int t0, int tid, float& mn) {
     // Round 3 (stamps: this tail was 37 % of a tile's time).  Whisper's 128 bands hold 1-2 bins below mel 64 and up to 9 above (394 in
     // all), so "one mel per thread, padded to 12" did 3.9x the band work and left the low-mel waves idle behind the high-mel ones.  Now
     // every wave takes a quarter of the frames and walks them twice: the 64 HIGH mels padded to the widest band among them, then the 64
@@ -109,11 +110,11 @@ __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const fl
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ka = max(ka, __shfl_xor(ka, o, 64)); kb = max(kb, __shfl_xor(kb, o, 64)); }
     float mx;
-    if (kb <= 9) mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, 9>(pw, cw, cband, out, tr, b, t0, 64 + lane, w);
-    else mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, 64 + lane, w);
-    if (ka <= 2) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 2>(pw, cw, cband, out, tr, b, t0, lane, w));
-    else if (ka <= 4) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 4>(pw, cw, cband, out, tr, b, t0, lane, w));
-    else mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, lane, w));
+    if (kb <= 9) mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, 9>(pw, cw, cband, out, tr, b, t0, 64 + lane, w, mn);
+    else mx = mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, 64 + lane, w, mn);
+    if (ka <= 2) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 2>(pw, cw, cband, out, tr, b, t0, lane, w, mn));
+    else if (ka <= 4) mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, 4>(pw, cw, cband, out, tr, b, t0, lane, w, mn));
+    else mx = fmaxf(mx, mel_tail_half<NFR, PITCH, TO, LAYOUT, KCMAX>(pw, cw, cband, out, tr, b, t0, lane, w, mn));
     if constexpr (LAYOUT == 0) {
         __syncthreads();
         for (int idx = tid; idx < NFR * NMEL; idx += 256) {
@@ -125,10 +126,28 @@ __device__ __forceinline__ float mel_tail(const float* __restrict__ pw, const fl
     return mx;
 }
 
+// The per-clip maximum of the log10 values (feature_extraction_whisper.py:160-164) without atomics or an init launch: every pass-1
+// workgroup leaves the (max, min) of the values it wrote in stats[clip][workgroup]; the floor launch reduces a clip's <= LM_STAT_SLOTS
+// maxima itself and, from the minima, knows which workgroups' tiles hold NO value below the floor -- those it never reads.
+constexpr int LM_STAT_SLOTS = 128;
+__device__ __forceinline__ void lm_store_stats(float* __restrict__ stats, int b, float mx, float mn) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    mx = wave_max(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+    if (lane == 0) { red[wave] = mx; red[4 + wave] = mn; }
+    __syncthreads();
+    if (tid == 0) {
+        stats[((long long)b * LM_STAT_SLOTS + blockIdx.x) * 2] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        stats[((long long)b * LM_STAT_SLOTS + blockIdx.x) * 2 + 1] = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+    }
+}
+
 template <typename TO, int LAYOUT>
 __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wav, int n_samples, long long wav_stride,
                                                     const float* __restrict__ tab, TO* __restrict__ out,
-                                                    int* __restrict__ clipmax) {
+                                                    float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);          // [NHOPROWS][HOPROW] samples, later [FT][PROW] power
     float* cw = xs + MAIN_FLOATS;                            // [CWMAX] compact mel weights
@@ -276,9 +295,9 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ wa
     __syncthreads();
 
     // ---- banded mel + log10 (weights and band table in LDS: no dependent global loads) ----
-    float mx = mel_tail<FT, PROW, TO, LAYOUT>(pw, cw, cband, out, tr, b, t0, tid);
-    mx = wave_max(mx);
-    if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
+    float mn = INFINITY;
+    const float mx = mel_tail<FT, PROW, TO, LAYOUT>(pw, cw, cband, out, tr, b, t0, tid, mn);
+    lm_store_stats(stats, b, mx, mn);
 }
 
 
@@ -341,9 +360,9 @@ __device__ __forceinline__ void dft5(float& r0, float& i0, float& r1, float& i1,
 }
 
 template <typename TO, int LAYOUT>
-__global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride,
-                                                        const float* __restrict__ tab, TO* __restrict__ out,
-                                                        int* __restrict__ clipmax, unsigned long long* dbg) {
+__global__ __launch_bounds__(256, (LAYOUT == 0 && LM_WG_PER_CU > 2) ? 2 : LM_WG_PER_CU)      // [B, 128, 3000] output: its transposition tile costs the third workgroup (it spilled 8 registers at 3)
+void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wav_stride, const float* __restrict__ tab, TO* __restrict__ out,
+                      float* __restrict__ stats, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef AFHIP_LOGMEL_STAMPS   /* diagnostic build: -DAFHIP_LOGMEL_STAMPS, tools/mel_stamps.py */
 #define LM_STAMP(k) do { if (dbg && blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
     const int k1p = (8 - k1) & 7;
     const int src0 = (lane & ~7) | (((k1p & 1) << 2) | (k1p & 2) | ((k1p >> 2) & 1));   // lane holding Z[200 - 25 k1]
 
-    float mx = -INFINITY;
+    float mx = -INFINITY, mn = INFINITY;
     for (int tile = blockIdx.x; tile < NTILE; tile += gridDim.x) {
     const int t0 = tile * FFT_FT;
     const int next = tile + (int)gridDim.x;
@@ -537,7 +556,7 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
 
     // ---- banded mel + log10 + affine, straight into the caller's tensor ----
     LM_STAMP(6);
-    mx = fmaxf(mx, mel_tail<FFT_FT, FFT_PROW, TO, LAYOUT>(xs, cw, cband, out, trt, b, t0, tid));
+    mx = fmaxf(mx, mel_tail<FFT_FT, FFT_PROW, TO, LAYOUT>(xs, cw, cband, out, trt, b, t0, tid, mn));
     LM_STAMP(7);
     if (next < NTILE) {
         __syncthreads();                                     // the power tile has been consumed: LDS takes the next samples
@@ -548,35 +567,51 @@ __global__ __launch_bounds__(256, LM_WG_PER_CU) void logmel_pass1_fft(const floa
         __syncthreads();
     }
     }
-    mx = wave_max(mx);
-    if (lane == 0 && mx > -INFINITY) atomicMax(clipmax + b, float_order_key(mx));
+    lm_store_stats(stats, b, mx, mn);
 }
 
-__global__ void logmel_init_max(int* clipmax, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) clipmax[i] = float_order_key(-INFINITY);
-}
-
-// Floor fix-up, in place: out = max(out, TO(((clipmax - 8) + 4) / 4)).  A clip's 128 x 3000 values are contiguous in both layouts;
-// one 16-byte chunk per lane, written back only where the floor changed something (silence / padding frames).
-template <typename TO>
-__global__ __launch_bounds__(256) void logmel_floor_kernel(TO* __restrict__ out, const int* __restrict__ clipmax) {
+// Floor fix-up, in place: out = max(out, TO(((clipmax - 8) + 4) / 4)).  Same grid as pass 1: workgroup g of clip b owns the frame tiles
+// g, g + gridDim.x, ... (TF frames each) that pass-1 workgroup g wrote, and stats[b][g].min tells whether any of their values lies below
+// the floor: if not (full-length audio: never; zero-padded clips: the padded tiles do) it returns after reading nwg (max, min) pairs.
+// Rewrites only the 16-byte chunks it changes.  Rounding is monotone: min >= floor before rounding implies stored >= TO(floor).
+template <typename TO, int LAYOUT>
+__global__ __launch_bounds__(256) void logmel_floor_kernel(TO* __restrict__ out, const float* __restrict__ stats, int nwg, int TF) {
     constexpr int EPC = 16 / sizeof(TO);
-    constexpr int CHUNKS = NFRAMES * NMEL / EPC;
-    const int b = blockIdx.y;
-    const float fl = ((float_from_key(clipmax[b]) - 8.0f) + 4.0f) / 4.0f;
+    __shared__ float s_max[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* st = stats + (long long)b * LM_STAT_SLOTS * 2;
+    float m = tid < nwg ? st[2 * tid] : -INFINITY;
+    m = wave_max(m);
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    const float cmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float fl = ((cmax - 8.0f) + 4.0f) / 4.0f;
     const float flr = to_f32<TO>(from_f32<TO>(fl));          // the floor as the output dtype holds it
-    TO* base = out + (long long)b * NFRAMES * NMEL;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < CHUNKS; c += gridDim.x * 256) {
-        u32x4 raw = ld16(base + (long long)c * EPC);
-        TO* v = reinterpret_cast<TO*>(&raw);
-        bool changed = false;
+    const float my_min = (st[2 * blockIdx.x + 1] + 4.0f) / 4.0f;
+    if (!(my_min < flr)) return;                              // nothing this workgroup's tiles hold is below the floor (workgroup-uniform)
+    const int ntile = (NFRAMES + TF - 1) / TF;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int t0 = tile * TF, nf = (t0 + TF <= NFRAMES) ? TF : NFRAMES - t0;
+        if constexpr (LAYOUT == 1) {
+            TO* base = out + ((long long)b * NFRAMES + t0) * NMEL;       // nf x 128 contiguous values
+            for (int c = tid; c < nf * NMEL / EPC; c += 256) {
+                u32x4 raw = ld16(base + (long long)c * EPC);
+                TO* v = reinterpret_cast<TO*>(&raw);
+                bool changed = false;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float x = to_f32<TO>(v[e]);
-            if (x < flr) { v[e] = from_f32<TO>(flr); changed = true; }
+                for (int e = 0; e < EPC; ++e) {
+                    const float x = to_f32<TO>(v[e]);
+                    if (x < flr) { v[e] = from_f32<TO>(flr); changed = true; }
+                }
+                if (changed) st16(base + (long long)c * EPC, raw);
+            }
+        } else {
+            for (int i = tid; i < nf * NMEL; i += 256) {                // [B, 128, 3000]: runs of nf frames per mel
+                const int mm = i / nf, f = i - mm * nf;
+                TO* pv = out + ((long long)b * NMEL + mm) * NFRAMES + t0 + f;
+                if (to_f32<TO>(*pv) < flr) *pv = from_f32<TO>(flr);
+            }
         }
-        if (changed) st16(base + (long long)c * EPC, raw);
     }
 }
 
@@ -633,19 +668,21 @@ extern "C" int afhip_log_mel_tables_host(void* host_buf, const float* filters_ho
 
 extern "C" size_t afhip_log_mel_workspace_bytes(int B) {
     if (B <= 0) return 0;
-    return ((size_t)B * sizeof(int) + 255) / 256 * 256;      // the per-clip running maxima; the log-mel values are written once, in place
+    return (size_t)B * LM_STAT_SLOTS * 2 * sizeof(float);    // (max, min) per clip and pass-1 workgroup; the log-mel values are written once, in place
 }
 
 namespace {
 template <typename TO, int LAYOUT>
-void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* out, const float* tables, int* clipmax, hipStream_t s) {
+void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* out, const float* tables, float* stats, hipStream_t s) {
+    int nwg, tf;
     if (afhip_opt(AFHIP_OPT_LOGMEL_DFT) == 1) {   // A/B switch: the folded-DFT MFMA form
         const size_t lds1 = sizeof(float) * (size_t)(MAIN_FLOATS + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FT * (NMEL + 1) : 0));
         static unsigned long long attr_done = 0;
         if (afhip_first_use_on_device(&attr_done))
             (void)hipFuncSetAttribute((const void*)logmel_pass1<TO, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((logmel_pass1<TO, LAYOUT>), dim3(cdiv(NFRAMES, FT), B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
-                           tables, out, clipmax);
+        nwg = cdiv(NFRAMES, FT); tf = FT;
+        hipLaunchKernelGGL((logmel_pass1<TO, LAYOUT>), dim3(nwg, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
+                           tables, out, stats);
     } else {
         const size_t lds1 = sizeof(float) * (size_t)(FFT_MAIN + 800 + Tables::CWMAX + 3 * NMEL + (LAYOUT == 0 ? FFT_FT * (NMEL + 1) : 0));
 #ifdef AFHIP_LOGMEL_STAMPS   /* diagnostic build only (tools/mel_stamps.py): 8 x s_memtime stamps of one workgroup */
@@ -657,12 +694,13 @@ void logmel_launch(const float* wav, int B, int n_samples, int wav_stride, TO* o
         // persistent over frame tiles: LM_WG_PER_CU workgroups per CU in one generation, each walking ceil(94 / gx) tiles
         int gx = cdiv(256 * LM_WG_PER_CU, B);
         gx = gx < 1 ? 1 : (gx > cdiv(NFRAMES, FFT_FT) ? cdiv(NFRAMES, FFT_FT) : gx);
+        nwg = gx; tf = FFT_FT;
         hipLaunchKernelGGL((logmel_pass1_fft<TO, LAYOUT>), dim3(gx, B), dim3(256), lds1, s, wav, n_samples, (long long)wav_stride,
-                           tables, out, clipmax, dbg);
+                           tables, out, stats, dbg);
     }
-    // floor fix-up: 8 workgroups x 256 lanes x 16 B per pass over a clip's 768 KB (bf16) / 1.5 MB (f32)
-    const int gf = cdiv(NFRAMES * NMEL / (16 / (int)sizeof(TO)), 256 * 4);
-    hipLaunchKernelGGL((logmel_floor_kernel<TO>), dim3(gf, B), dim3(256), 0, s, out, clipmax);
+    // floor fix-up on the grid of pass 1: a workgroup re-reads only the tiles its pass-1 twin reported a value below the floor for
+    static_assert(NFRAMES / FFT_FT + 1 <= LM_STAT_SLOTS && NFRAMES / FT + 1 <= LM_STAT_SLOTS, "stats slots per clip");
+    hipLaunchKernelGGL((logmel_floor_kernel<TO, LAYOUT>), dim3(nwg, B), dim3(256), 0, s, out, stats, nwg, tf);
 }
 }  // namespace
 
@@ -676,8 +714,8 @@ extern "C" int afhip_log_mel(const float* wav, int B, int n_samples, int wav_str
     AFHIP_CHECK(out_dtype == AFHIP_F32 || out_dtype == AFHIP_BF16, "afhip_log_mel: bad dtype %d", out_dtype);
     AFHIP_CHECK(((uintptr_t)tables % 16) == 0 && ((uintptr_t)mel_out % 16) == 0, "afhip_log_mel: tables and mel_out must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int* clipmax = reinterpret_cast<int*>(workspace);
-    hipLaunchKernelGGL(logmel_init_max, dim3(cdiv(B, 256)), dim3(256), 0, s, clipmax, B);
+    AFHIP_CHECK(((uintptr_t)workspace % 8) == 0, "afhip_log_mel: workspace must be 8-byte aligned");
+    float* clipmax = reinterpret_cast<float*>(workspace);      // [B][LM_STAT_SLOTS][2]: (max, min) per pass-1 workgroup, written before it is read
     if (out_dtype == AFHIP_F32) {
         if (layout == 0) logmel_launch<float, 0>(wav, B, n_samples, wav_stride, (float*)mel_out, tables, clipmax, s);
         else logmel_launch<float, 1>(wav, B, n_samples, wav_stride, (float*)mel_out, tables, clipmax, s);

@@ -187,7 +187,8 @@ LLM_7B = dict(architectures=["Qwen2ForCausalLM"], hidden_size=3584, num_hidden_l
               num_key_value_heads=4, intermediate_size=18944, rope_theta=1e6, rms_norm_eps=1e-6, vocab_size=152064)
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
-MEL_BYTES_PER_CLIP = 480000 * 4 + 128 * 3000 * 4      # read wav + write f32 mel
+MEL_BYTES_PER_CLIP_SURVEY = 480000 * 4 + 128 * 3000 * 4      # read wav + write an f32 mel
+MEL_BYTES_PER_CLIP = 480000 * 4 + 128 * 3000 * 2             # what the timed launch moves: f32 wav in, bf16 mel out (the encoder's dtype)
 
 
 class BoardSampler:
@@ -405,20 +406,25 @@ def build_llm_7b(device, enc):
     return model, len(vocab)
 
 
-def decode_bytes_per_step(n_vocab, B, ctx, wbytes):
+def decode_bytes_per_step(head_rows, B, ctx, wbytes):
+    """layer weights + the lm_head rows the step streams (text decode: rows below 256 + text vocab, the 8 x 1025
+    audio-code rows behind them are never allowed) + the K/V of the context, once per step."""
     H, I, nl = LLM_7B["hidden_size"], LLM_7B["intermediate_size"], LLM_7B["num_hidden_layers"]
     kvw = LLM_7B["num_key_value_heads"] * (H // LLM_7B["num_attention_heads"])
-    w_elems = nl * (H * H * 2 + 2 * H * kvw + 3 * H * I) + n_vocab * H
+    w_elems = nl * (H * H * 2 + 2 * H * kvw + 3 * H * I) + head_rows * H
     return w_elems * wbytes + B * ctx * nl * 2 * kvw * 2
 
 
 def decode_traffic(label):
-    """HBM bytes per decode step from the committed rocprofv3 --pmc passes (profiles/r02_decode_traffic_pmc.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_decode_traffic_pmc.json")) as f:
-            return json.load(f)["per_step_bytes"][label]
-    except (OSError, KeyError, ValueError):
-        return None
+    """(HBM bytes per decode step, file) from the committed rocprofv3 --pmc passes over the decode step of the newest round that has
+    them (profiles/rNN_decode_traffic_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes), or (None, None)."""
+    for name in ("r04_decode_traffic_pmc.json", "r02_decode_traffic_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["per_step_bytes"][label], name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def decode_leg(device, model, n_vocab, fe, B, n_steps, warm, config_name):
@@ -460,11 +466,15 @@ def decode_leg(device, model, n_vocab, fe, B, n_steps, warm, config_name):
         hyp, _, cache = model._greedy_device_loop(hyp[:, -1:, :], cache, "text", n_steps, poll=10 ** 9)
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
-        step_bytes = decode_bytes_per_step(n_vocab, B, cache.length - n_steps // 2, wbytes)
+        model._allowed_intervals("text")
+        head_rows = model._allowed_hi.get("text") or n_vocab
+        step_bytes = decode_bytes_per_step(head_rows, B, cache.length - n_steps // 2, wbytes)
         gbs = step_bytes * n_steps / dt_s / 1e9
+        traffic, traffic_file = decode_traffic(f"B{B}_{'fp8' if key else 'bf16'}")
         leg = {"weights": label, "tokens_per_s": B * n_steps / dt_s, "ms_per_step": dt_s / n_steps * 1e3,
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                            "traffic": decode_traffic(f"B{B}_{'fp8' if key else 'bf16'}"), "bytes_per_step": step_bytes}}
+                            "traffic": traffic, "traffic_unit": f"HBM bytes per step, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_file}" if traffic_file else None,
+                            "bytes_per_step": step_bytes, "lm_head_rows": head_rows}}
         if key is None:
             res.update(leg)
         else:
@@ -622,14 +632,18 @@ def decode_only_workload(args, device, enc, fe):
     torch.cuda.synchronize()
     dt_s = time.perf_counter() - t0
     wbytes = 1 if args.decode_fp8 else 2
-    step_bytes = decode_bytes_per_step(n_vocab, B, cache.length - n_steps // 2, wbytes)
+    model._allowed_intervals("text")
+    head_rows = model._allowed_hi.get("text") or n_vocab
+    step_bytes = decode_bytes_per_step(head_rows, B, cache.length - n_steps // 2, wbytes)
     gbs = step_bytes * n_steps / dt_s / 1e9
+    traffic, traffic_file = decode_traffic(f"B{B}_{'fp8' if args.decode_fp8 else 'bf16'}")
     return {"metric": "decode tokens/sec (AF3-7B shape greedy decode loop only)", "value": B * n_steps / dt_s, "unit": "tokens/s", "n_gpus": 1,
             "steps": n_steps, "warmup": warm, "ms_per_step": dt_s / n_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.decode_fp8 else "bf16 activations, e4m3 weights", "data": "synthetic",
             "config": {"workload": f"AF3-7B greedy decode only, B={B}, ctx ~{cache.length - n_steps // 2}", "batch": B, "prompt_tokens": T},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                         "traffic": decode_traffic(f"B{B}_{'fp8' if args.decode_fp8 else 'bf16'}"), "bytes_per_step": step_bytes},
+                         "traffic": traffic, "traffic_unit": f"HBM bytes per step, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_file}" if traffic_file else None,
+                         "bytes_per_step": step_bytes, "lm_head_rows": head_rows},
             "cpu_baseline": None}
 
 
@@ -705,7 +719,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    L.check(lib.afhip_prof_enable(args.steps * (4 * ENC_CFG["encoder_layers"] + 2) + 8))
+    L.check(lib.afhip_prof_enable(args.steps * (5 * ENC_CFG["encoder_layers"] + 2) + 8))       # 4 GEMMs + 1 attention per layer, 2 stem GEMMs
     board = BoardSampler(device.index if device.index is not None else 0)
     board.start()
     t0 = time.perf_counter()
@@ -721,6 +735,9 @@ def main():
     n_o, ms_o, fl_o = C.c_int(), C.c_double(), C.c_double()
     L.check(lib.afhip_prof_collect(L.BF16, C.byref(n_o), C.byref(ms_o), C.byref(fl_o)))
     L.check(lib.afhip_prof_collect(L.BF16 | 0x100, C.byref(n_l), C.byref(ms), C.byref(fl)))
+    # the encoder attention kernel AS IT IS PAID inside the timed steps (HIP events around each launch, afhip.h: AFHIP_PROF_ATTN)
+    n_a, ms_a, fl_a = C.c_int(), C.c_double(), C.c_double()
+    L.check(lib.afhip_prof_collect(0x400, C.byref(n_a), C.byref(ms_a), C.byref(fl_a)))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -830,9 +847,17 @@ def main():
                                         "avg_launch_ms": ms_o.value / max(1, n_o.value),
                                         "tflops": fl_o.value / (ms_o.value * 1e-3) / 1e12 if ms_o.value > 0 else 0.0},
                          "board": board_info},
+            "attn": {"kernel": "attn_enc64_kernel (encoder attention, one launch per layer), timed with HIP events around each launch INSIDE the timed steps",
+                     "launches": n_a.value, "avg_launch_ms": ms_a.value / max(1, n_a.value),
+                     "achieved": (fl_a.value / (ms_a.value * 1e-3) / 1e12) if ms_a.value > 0 else 0.0, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (fl_a.value / (ms_a.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if ms_a.value > 0 else 0.0,
+                     "share_of_step": ms_a.value / (elapsed * 1e3) if world == 1 else None},
             "stages": {"mel_ms": mel_ms, "mel_audio_s_per_s": B * 30.0 / (mel_ms * 1e-3),
                        "mel_roofline": {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": mel_gbs / PEAK_HBM_GBS, "traffic": mel_traffic, "bytes_per_clip": MEL_BYTES_PER_CLIP},
+                                        "frac": mel_gbs / PEAK_HBM_GBS, "traffic": mel_traffic, "bytes_per_clip": MEL_BYTES_PER_CLIP,
+                                        "bytes": "wav f32 in + mel in the dtype the timed launch writes (bf16): 2 688 000 B per 30-s clip; "
+                                                 "SURVEY 8(d)'s 3 456 000 B assumes an f32 mel",
+                                        "traffic_over_bytes": (mel_traffic / (MEL_BYTES_PER_CLIP * B)) if mel_traffic else None},
                        "encoder_fp8": enc8,
                        "encoder_mixed_lengths": enc_mixed,
                        "encoder_ms": enc_ms, "encoder_audio_s_per_s": B * 30.0 / (enc_ms * 1e-3),

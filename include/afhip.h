@@ -128,6 +128,7 @@ int afhip_gemm(const afhip_gemm_args* args, void* stream);
  * roofline leg can quote that kernel alone (its rocprofv3 rows) and the remaining launches separately. */
 #define AFHIP_PROF_PINGPONG 0x100
 #define AFHIP_PROF_FP8 0x200       /* e4m3-operand launches are recorded as AFHIP_PROF_FP8 | AFHIP_PROF_PINGPONG */
+#define AFHIP_PROF_ATTN 0x400      /* launches of the encoder attention kernel (attention_enc.hip); flops = 4 Tq Tk hd per head and clip */
 int afhip_prof_enable(int max_launches);
 int afhip_prof_collect(int dtype, int* n_launches, double* total_ms, double* total_flops);
 
