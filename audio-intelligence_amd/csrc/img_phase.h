@@ -60,6 +60,7 @@ struct ImgPhase {
     int ig, iu, ij;
     float ep_b[NI], ep_r[NI], ep_g[NI], ep_s[NI];
     float ssp[2];      // this lane's share of the partial sums of squares of rows wave, wave + 8
+    float ssv[RM / 8][4];  // ... as loaded (up to 256 partials per row: four per lane), summed when the K loop is about to start
     f32x4 acc[NT];
     int cu, cj;
     float am_best, ss_acc;
@@ -146,6 +147,19 @@ struct ImgPhase {
         }
     }
 
+    __device__ __forceinline__ void load_ss() {
+#pragma unroll
+        for (int ri = 0; ri < RM / 8; ++ri) {
+            const int m = wave + 8 * ri;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = lane + 64 * k;
+                const int jc = j < p.ss_n ? j : p.ss_n - 1;                 // clamped: unconditional loads
+                const float v = COH ? __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + jc) * 4, 0, 16)) : p.ss_in[m * p.ss_n + jc];
+                ssv[ri][k] = j < p.ss_n ? v : 0.f;
+            }
+        }
+    }
     // Indices and the first weight window.  A_READY = false: the image is still being written by other workgroups of this launch --
     // only weights (and own-data residuals) move until run().
     template <bool A_READY> __device__ __forceinline__ void begin() {
@@ -164,6 +178,9 @@ struct ImgPhase {
                   : (long long)((q * RM + (c16 & (RM - 1))) << 4);
         ST_STAMP(0);
         ig = 0; iu = 0; ij = 0;
+        // the partial sums of squares go out BEFORE the weight window: vmcnt retires in order, and behind the window their first use
+        // drained all of it (gate/up: 5.8 us from launch to first MFMA, then a refill bubble)
+        if constexpr (RMS && A_READY) load_ss();
         if (my_units > 0) set_rows(0);
         // chained (A_READY = false): wave 0 is the wave that polls the grid barrier -- a poll's result retires in order BEHIND every
         // vector load the wave has in flight, so with a weight window of its own it would see the barrier open only after that whole
@@ -273,14 +290,14 @@ struct ImgPhase {
             }
         }
         if constexpr (RMS) {
-            // partial sums of squares of rows wave (and wave + 8): [row][ss_n], summed lane-strided here, across the wave at the first unit's end
+            if constexpr (!A_READY) load_ss();
+            // partial sums of squares of rows wave (and wave + 8): lane-strided here, across the wave at the first unit's end
 #pragma unroll
             for (int ri = 0; ri < RM / 8; ++ri) {
-                float t = 0.f;
+                float t = ((ssv[ri][0] + ssv[ri][1]) + ssv[ri][2]) + ssv[ri][3];
                 const int m = wave + 8 * ri;
-                for (int j = lane; j < p.ss_n; j += 64)
-                    t += __uint_as_float(COH ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + j) * 4, 0, 16)
-                                             : __float_as_uint(p.ss_in[m * p.ss_n + j]));
+                for (int j = lane + 256; j < p.ss_n; j += 64)           // more than 256 producing workgroups: the rest, the slow way
+                    t += COH ? __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + j) * 4, 0, 16)) : p.ss_in[m * p.ss_n + j];
                 ssp[ri] = t;
             }
         }
