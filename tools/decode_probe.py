@@ -31,7 +31,7 @@ for rnd in range(int(os.environ.get("PROBE_ROUNDS", "1"))):
         if "=" in kv:
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
     print("variant", var, "round", rnd)
-    for fp8 in ((False, True) if not os.environ.get("PROBE_BF16_ONLY") else (False,)):
+    for fp8 in ((True,) if os.environ.get("PROBE_FP8_ONLY") else ((False, True) if not os.environ.get("PROBE_BF16_ONLY") else (False,))):
       model.enable_fp8_decode(fp8)
       cache.length = ctx
       hyp, _, cache = model._greedy_device_loop(tok, cache, "text", 4, poll=10 ** 9)
