@@ -252,7 +252,7 @@ def pmc_traffic():
     every dispatch and need the profiler as the parent process, so they are collected offline on the same build and only READ
     here; (None, None, None) when no file is present."""
     base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name, key in (("r03_hbm_traffic_pmc.json", "kernels_r03"), ("r02_hbm_traffic_pmc.json", "kernels_r02"), ("r01_hbm_traffic_pmc.json", "kernels_r01_e")):
+    for name, key in (("r04_hbm_traffic_pmc.json", "kernels_r04"), ("r03_hbm_traffic_pmc.json", "kernels_r03"), ("r02_hbm_traffic_pmc.json", "kernels_r02"), ("r01_hbm_traffic_pmc.json", "kernels_r01_e")):
         try:
             with open(os.path.join(base, name)) as f:
                 k = json.load(f)[key]
