@@ -501,6 +501,13 @@ def decode_leg(device, model, n_vocab, fe, B, n_steps, warm, config_name):
     return res
 
 
+def _rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:       # noqa: BLE001 -- a build without the binding: the record says so
+        return None
+
+
 def long_audio_workload(args, device, dist, rank, world, enc, fe, with_llm=True, steps=None, warmup=None):
     """BASELINE configs[3]: 4 x 10-minute clips = 80 windows of 30 s, sharded over the ranks in contiguous blocks; each rank
     generates / uploads ONLY its own block, runs log-mel + encoder on it, and ONE all_gather_into_tensor returns every window's
@@ -560,6 +567,12 @@ def long_audio_workload(args, device, dist, rank, world, enc, fe, with_llm=True,
         sent = (world - 1) * shard
         res["collective"] = {"op": "all_gather_into_tensor (RCCL over xGMI)" if not rehearsal else "all_gather_into_tensor (gloo REHEARSAL on one GPU: not a measurement)",
                              "backend": dist.get_backend() if dist is not None else None, "ranks": world,
+                             # what the process group itself reports, and the algorithm / protocol knobs RCCL ran under (unset = RCCL's
+                             # own choice: the direct one-hop pattern vs ring question of SURVEY 5 is left to it and recorded here)
+                             "ranks_seen_by_process_group": dist.get_world_size() if dist is not None else 1,
+                             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                     "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")},
+                             "rccl_version": _rccl_version() if not rehearsal else None,
                              "shard_bytes": shard, "ms": ms, "ms_min": min(gather_ms), "bytes_sent_per_rank": sent,
                              "GBps_per_rank": sent / (ms * 1e-3) / 1e9, "xgmi_peak_GBps_per_rank": 7 * 153.0,
                              "frac_of_xgmi": sent / (ms * 1e-3) / 1e9 / (7 * 153.0),
