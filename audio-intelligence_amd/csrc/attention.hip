@@ -567,13 +567,13 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
     const int d = threadIdx.x;
     if (p.seq_pos) { const int live = (p.seq_pos[b] + 1 + p.key_split - 1) / p.key_split; n_split = live < n_split ? live : n_split; }
     auto slot_of = [&](int sp) { return (((long long)sp * p.B + b) * p.n_q + hq) * 32 + qrow; };
-    if (n_split <= 8) {
-        // short contexts (the 7B decode step: 7 key ranges): every load of the merge -- the (max, sum) pairs and this thread's O column of
+    if (n_split <= 16) {
+        // short contexts (the 7B decode step: 7 key ranges of 128 keys, 14 of 64): every load of the merge -- the (max, sum) pairs and this thread's O column of
         // all ranges -- is issued before the first is used: one memory round trip instead of three dependent ones (5.7 us per layer for
         // 0.8 MB).  Same maximum, same weights, same fma chains in range order as the general path below: same bits.
-        float ms[8], ls[8], vs[8];
+        float ms[16], ls[16], vs[16];
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
+        for (int sp = 0; sp < 16; ++sp) {
             const long long slot = slot_of(sp < n_split ? sp : 0);
             ms[sp] = p.part_ml[slot * 2];
             ls[sp] = p.part_ml[slot * 2 + 1];
@@ -581,10 +581,10 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
         }
         float m = -INFINITY;
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) m = sp < n_split ? fmaxf(m, ms[sp]) : m;
+        for (int sp = 0; sp < 16; ++sp) m = sp < n_split ? fmaxf(m, ms[sp]) : m;
         float l = 0.f, o = 0.f;
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
+        for (int sp = 0; sp < 16; ++sp) {
             if (sp < n_split) {
                 const float w = (ms[sp] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms[sp] - m) * p.scale_log2);
                 l = fmaf(ls[sp], w, l);

@@ -11,14 +11,15 @@ size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 // merge of the decode attention's key-range partials: by the last-arriving workgroup inside the attention launch (1) or by a second
 // launch (0, the default: the in-launch form measured slower).  Option DECODE_MERGE (common.h) selects it.
 #define DECODE_IN_LAUNCH_MERGE (afhip_opt(AFHIP_OPT_DECODE_MERGE) == 1)
-#ifndef DECODE_KEY_SPLIT
-#define DECODE_KEY_SPLIT 128   /* keys per workgroup of the split-context decode attention (multiple of 64); 256 / 128 / 64 measured 3.85 / 3.79 / 3.84 ms per 7B step */
+// keys per workgroup of the split-context decode attention (a multiple of 64).  DECODE_KEY_SPLIT_MIN sizes the partial workspace; the run-time
+// choice is option DECODE_KEY_SPLIT (0 = DECODE_KEY_SPLIT_DEFAULT).
+#define DECODE_KEY_SPLIT_MIN 64
+#ifndef DECODE_KEY_SPLIT_DEFAULT
+#define DECODE_KEY_SPLIT_DEFAULT 128
 #endif
-
-// option DECODE_KEY_SPLIT = keys per workgroup at run time (a multiple of DECODE_KEY_SPLIT, which sized the workspace)
 static int decode_key_split() {
     const int v = afhip_opt(AFHIP_OPT_DECODE_KEY_SPLIT);
-    return (v >= DECODE_KEY_SPLIT && v % DECODE_KEY_SPLIT == 0) ? v : DECODE_KEY_SPLIT;
+    return (v >= DECODE_KEY_SPLIT_MIN && v % DECODE_KEY_SPLIT_MIN == 0) ? v : DECODE_KEY_SPLIT_DEFAULT;
 }
 
 struct LlmWs {
@@ -47,8 +48,8 @@ LlmWs carve(const afhip_llm_weights* w, int rows, char* base, int max_ctx = 0) {
     ws.att = take((size_t)rows * w->n_q * w->hd * sz);
     ws.act = take((size_t)rows * 2 * w->inter * sz);
     ws.act2 = take((size_t)rows * w->inter * sz);
-    // decode partials: ceil(ctx/DECODE_KEY_SPLIT) splits x rows(B) x n_kv x 32 x (hd+2) f32 (only used when T == 1)
-    ws.part_bytes = max_ctx > 0 ? (size_t)((max_ctx + DECODE_KEY_SPLIT - 1) / DECODE_KEY_SPLIT) * rows * w->n_kv * 32 * (w->hd + 2) * sizeof(float) : 0;
+    // decode partials: ceil(ctx / DECODE_KEY_SPLIT_MIN) splits x rows(B) x n_kv x 32 x (hd+2) f32 (only used when T == 1)
+    ws.part_bytes = max_ctx > 0 ? (size_t)((max_ctx + DECODE_KEY_SPLIT_MIN - 1) / DECODE_KEY_SPLIT_MIN) * rows * w->n_kv * 32 * (w->hd + 2) * sizeof(float) : 0;
     ws.part = take(ws.part_bytes);
     ws.ticket_bytes = max_ctx > 0 ? (size_t)w->n_layers * rows * w->n_kv * sizeof(int) : 0;
     ws.ticket = (int*)take(ws.ticket_bytes);

@@ -8,6 +8,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("PROBE_LIB"):            # same-box A/B of two builds of the library
+    from audio_intelligence_amd import _lib as _L
+    _L.load_library(os.environ["PROBE_LIB"])
 import bench  # noqa: E402
 from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig  # noqa: E402
 
