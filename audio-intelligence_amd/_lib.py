@@ -81,7 +81,7 @@ class KvCache(C.Structure):
 class DecodeState(C.Structure):
     _fields_ = [("prev_token", C.c_void_p), ("out_tokens", C.c_void_p), ("finished_at", C.c_void_p),
                 ("allowed", C.c_void_p), ("n_iv", C.c_int), ("eos_id", C.c_int), ("eot_id", C.c_int),
-                ("seq_pos", C.c_void_p), ("step_counter", C.c_void_p), ("head_rows", C.c_int), ("status", C.c_void_p)]
+                ("seq_pos", C.c_void_p), ("step_counter", C.c_void_p), ("head_rows", C.c_int)]
 
 
 class SampleArgs(C.Structure):

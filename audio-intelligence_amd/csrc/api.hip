@@ -38,7 +38,7 @@ const OptDef kOpts[AFHIP_OPT_COUNT] = {
     {"ATTN_LAG", 1},                // lagged-maximum softmax of the generic bf16 hd-64 prescaled form
     {"ATTN_ENC64", 1},              // the one-wave-per-SIMD encoder attention (attention_enc.hip)
     {"ENC64_ONE_BLOCK_PER_WG", 0},  // encoder attention: one query block per workgroup instead of the persistent walk
-    {"DECODE_CHAIN", 1},            // decode step: 0 = round-3 launches, 1 = imaged phases (one per launch), 2 = chained behind grid barriers
+    {"DECODE_IMAGED", 1},           // decode step GEMMs: 1 = persistent imaged phases (decode_phases.hip), 0 = the round-3 launches over row-major activations
     {"DECODE_MERGE", 0},            // split-context decode attention: merge by the last-arriving workgroup inside the launch
     {"DECODE_KEY_SPLIT", 0},        // keys per workgroup of the split-context decode attention (0 = the built-in 128)
     {"FP8_MASK", 6},                // e4m3 encoder mode: which projections take e4m3 operands (bit 0 qkv, 1 out, 2 fc1, 3 fc2)

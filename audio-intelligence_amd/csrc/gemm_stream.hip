@@ -2,7 +2,7 @@
 // Replaces, per decoder layer of ParallelLLM._step (lm/parallel.py:570-597 over modeling_qwen2.py:195-235, 35-49): q|k|v with the
 // RMSNorm in front of it and its bias, the o projection + residual, gate/up with RMSNorm + SwiGLU, the down projection + residual;
 // and the lm_head (lm/parallel.py:592).  The phase itself (weight window, activation image / slots, K-slice combine, epilogues) is
-// stream_phase.h; decode_chain.hip runs the same phases back to back inside one launch.
+// stream_phase.h; the decode step itself runs img_phase.h (activations handed over as fragment-order images, decode_phases.hip).
 #include "stream_phase.h"
 #include <stdlib.h>
 
@@ -14,9 +14,9 @@ using stream::KS;
 template <int AMODE, int NT, bool PAIR, bool SLOT, int RM, int DEPTH>
 __global__ __launch_bounds__(512) void skinny_stream_kernel(SkinnyP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    stream::StreamPhase<AMODE, NT, PAIR, SLOT, RM, DEPTH, false> ph(p, smem);
-    ph.template begin<true>();
-    ph.template run<true>();
+    stream::StreamPhase<AMODE, NT, PAIR, SLOT, RM, DEPTH> ph(p, smem);
+    ph.begin();
+    ph.run();
 }
 
 constexpr size_t STREAM_LDS_MAX = 156 * 1024;
@@ -34,7 +34,7 @@ bool launch_rm(const SkinnyP& p, int amode, int grid, hipStream_t s) {
     // K steps in flight per wave.  The narrow projections (one unit per workgroup, 7 steps per wave at K = 3584) put a wave's whole K
     // share in flight at once: a window of 4 pays a second HBM round trip for steps 4..6.  Four tiles per step: 2 (64 weight registers)
     constexpr int D = (NT <= 2 && !PAIR) ? 7 : (NT == 4 ? 2 : 4);
-    const size_t fixed = stream::StreamPhase<SKINNY_A_PLAIN, NT, PAIR, false, RM, D, false>::fixed_lds();
+    const size_t fixed = stream::StreamPhase<SKINNY_A_PLAIN, NT, PAIR, false, RM, D>::fixed_lds();
     const size_t img = (size_t)RM * p.K * 2;
     if (fixed + img <= STREAM_LDS_MAX) {
         if (amode == SKINNY_A_RMSNORM) launch<SKINNY_A_RMSNORM, NT, PAIR, false, RM, D>(p, grid, fixed + img, s);

@@ -18,6 +18,11 @@
 
 namespace stream {
 
+__device__ __forceinline__ u32x4 ld16g(const char* base, long long off) { return *reinterpret_cast<const u32x4*>(base + off); }
+__device__ __forceinline__ float ld_bf16g(const char* base, long long off) { return (float)*reinterpret_cast<const bf16*>(base + off); }
+__device__ __forceinline__ void st_bf16g(char* base, long long off, float v) { *reinterpret_cast<bf16*>(base + off) = (bf16)v; }
+__device__ __forceinline__ void st_f32g(char* base, long long off, float v) { *reinterpret_cast<float*>(base + off) = v; }
+
 // byte offset of element (row m, column k) in a fragment-order image of RM rows
 __device__ __forceinline__ long long img_off(int RM, int m, int k) {
     return (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + m) << 4) + ((k & 7) << 1);
@@ -40,7 +45,7 @@ struct ImgDesc {
 // still reads 32 contiguous bytes of its weight row; the 32 values are widened to bf16 in registers and meet the lane's four A fragments
 // -- chunks of the SAME bf16 image (64-step 2 s + (q >> 1), column group 2 (q & 1) + (c >> 1), half c & 1) -- in four MFMAs.  K / 128 need not
 // divide by the eight waves: wave w takes steps w, w + 8, ... of every unit and all of them meet at the unit's combine barrier.
-template <int NT, bool PAIR, bool RMS, int RM, int DEPTH, bool COH, bool W8 = false>
+template <int NT, bool PAIR, bool RMS, int RM, int DEPTH, bool W8 = false>
 struct ImgPhase {
     static_assert(RM == 8 || RM == 16, "activation image rows");
     static_assert(!PAIR || NT == 2, "SwiGLU pairs: one gate tile + one up tile");
@@ -55,7 +60,6 @@ struct ImgPhase {
     int tid, lane, wave, c16, q, TR, gates, spw, my_units, total, cr;
     const char* wrow[NT];
     Regs r[DEPTH];
-    int sidx[DEPTH];
     long long aofs;
     int ig, iu, ij;
     float ep_b[NI], ep_r[NI], ep_g[NI], ep_s[NI];
@@ -111,24 +115,23 @@ struct ImgPhase {
             // fragment c of lane q: image chunk (64-step 2 s + (q >> 1), column group 2 (q & 1) + (c >> 1), half c & 1)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                x.a[c] = hld16<COH>(p.A, aofs + (long long)s * (RM * 256) + (c & 1) * (RM * 64) + (c >> 1) * (RM * 16));
+                x.a[c] = ld16g(p.A, aofs + (long long)s * (RM * 256) + (c & 1) * (RM * 64) + (c >> 1) * (RM * 16));
         } else {
-            x.a[0] = hld16<COH>(p.A, aofs + (long long)s * (RM * 128));
-            x.a[1] = hld16<COH>(p.A, aofs + (long long)s * (RM * 128) + RM * 64);
+            x.a[0] = ld16g(p.A, aofs + (long long)s * (RM * 128));
+            x.a[1] = ld16g(p.A, aofs + (long long)s * (RM * 128) + RM * 64);
         }
     }
-    template <bool WITH_A> __device__ __forceinline__ int issue(Regs& x) {
+    __device__ __forceinline__ void issue(Regs& x) {
         const int s = wave + NW * ij;
         const long long koff = (long long)s * 128 + q * 32;          // 32 bytes per lane and step in either weight format
 #pragma unroll
         for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
-        if constexpr (WITH_A) issue_a(x, s);
+        issue_a(x, s);
         ++ig;
         if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
-        return s;
     }
     // bias / residual / image gain of this thread's epilogue items (o = tid (+ 512): reg = o & 3, column = (o >> 2) & 15, row group =
-    // (o >> 6) & 3, tile = o >> 8), fetched when a unit STARTS.  In a chain the residual a thread adds is the element it wrote itself.
+    // (o >> 6) & 3, tile = o >> 8), fetched when a unit STARTS.
     __device__ __forceinline__ void fetch_epi(int ui) {
         if constexpr (!PAIR) {
             const int u = (int)blockIdx.x + ui * (int)gridDim.x;
@@ -141,7 +144,7 @@ struct ImgPhase {
                 const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional
                 ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
                 ep_g[i] = p.img_gain ? (float)reinterpret_cast<const bf16*>(p.img_gain)[nc] : 1.f;
-                ep_r[i] = p.res ? hld_bf16<COH>(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
+                ep_r[i] = p.res ? ld_bf16g(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
                 ep_s[i] = W8 ? p.w_scale[nc] : 1.f;
             }
         }
@@ -155,14 +158,13 @@ struct ImgPhase {
             for (int k = 0; k < 4; ++k) {
                 const int j = lane + 64 * k;
                 const int jc = j < p.ss_n ? j : p.ss_n - 1;                 // clamped: unconditional loads
-                const float v = COH ? __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + jc) * 4, 0, 16)) : p.ss_in[m * p.ss_n + jc];
+                const float v = p.ss_in[m * p.ss_n + jc];
                 ssv[ri][k] = j < p.ss_n ? v : 0.f;
             }
         }
     }
-    // Indices and the first weight window.  A_READY = false: the image is still being written by other workgroups of this launch --
-    // only weights (and own-data residuals) move until run().
-    template <bool A_READY> __device__ __forceinline__ void begin() {
+    // Indices, the partial sums of squares, the first weight window, the epilogue operands of the first unit.
+    __device__ __forceinline__ void begin() {
         tid = threadIdx.x; lane = tid & 63; wave = tid >> 6;
         c16 = lane & 15; q = lane >> 4;
         TR = p.tile_rows;
@@ -180,18 +182,11 @@ struct ImgPhase {
         ig = 0; iu = 0; ij = 0;
         // the partial sums of squares go out BEFORE the weight window: vmcnt retires in order, and behind the window their first use
         // drained all of it (gate/up: 5.8 us from launch to first MFMA, then a refill bubble)
-        if constexpr (RMS && A_READY) load_ss();
+        if constexpr (RMS) load_ss();
         if (my_units > 0) set_rows(0);
-        // chained (A_READY = false): wave 0 is the wave that polls the grid barrier -- a poll's result retires in order BEHIND every
-        // vector load the wave has in flight, so with a weight window of its own it would see the barrier open only after that whole
-        // window had landed (3-5 us under the stream); it issues its window in run() instead
-        if (A_READY || wave != 0) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                sidx[d] = 0;
-                if (ig < total) sidx[d] = issue<A_READY>(r[d]);
-            }
-        }
+        for (int d = 0; d < DEPTH; ++d)
+            if (ig < total) issue(r[d]);
         ST_STAMP(1);
         if (my_units > 0) fetch_epi(0);
     }
@@ -235,8 +230,8 @@ struct ImgPhase {
                         g *= p.w_scale[ng]; uu *= p.w_scale[ng + 32];
                     }
                     const float y = silu(g) * uu;
-                    if (p.img_out) hst_bf16<COH>(p.img_out, img_off(RM, mrow, gi), y);
-                    else hst_bf16<COH>(p.C, ((long long)mrow * p.ldc + gi) * 2, y);
+                    if (p.img_out) st_bf16g(p.img_out, img_off(RM, mrow, gi), y);
+                    else st_bf16g(p.C, ((long long)mrow * p.ldc + gi) * 2, y);
                 }
             }
         } else {
@@ -255,13 +250,13 @@ struct ImgPhase {
                         if (p.bias) v += ep_b[i];
                         if (p.res) v += ep_r[i];
                         if (p.C) {
-                            if (p.out_f32) hst_f32<COH>(p.C, ((long long)mm * p.ldc + nn) * 4, v);
-                            else hst_bf16<COH>(p.C, ((long long)mm * p.ldc + nn) * 2, v);
+                            if (p.out_f32) st_f32g(p.C, ((long long)mm * p.ldc + nn) * 4, v);
+                            else st_bf16g(p.C, ((long long)mm * p.ldc + nn) * 2, v);
                         }
                         if (p.img_out) {
                             // the stored (bf16) value is what the next RMSNorm sees: gain applied to it, its square summed
                             const float xb = (float)(bf16)v;
-                            hst_bf16<COH>(p.img_out, img_off(RM, mm, nn), xb * ep_g[i]);
+                            st_bf16g(p.img_out, img_off(RM, mm, nn), xb * ep_g[i]);
                             ss_acc += xb * xb;
                         }
                         if (p.am_val) {
@@ -277,27 +272,14 @@ struct ImgPhase {
         }
     }
 
-    template <bool A_READY> __device__ __forceinline__ void run() {
-        if constexpr (!A_READY) {
-            if (wave != 0) {
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d)
-                    if (d < total) issue_a(r[d], sidx[d]);
-            } else {
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d)
-                    if (ig < total) issue<true>(r[d]);
-            }
-        }
+    __device__ __forceinline__ void run() {
         if constexpr (RMS) {
-            if constexpr (!A_READY) load_ss();
             // partial sums of squares of rows wave (and wave + 8): lane-strided here, across the wave at the first unit's end
 #pragma unroll
             for (int ri = 0; ri < RM / 8; ++ri) {
                 float t = ((ssv[ri][0] + ssv[ri][1]) + ssv[ri][2]) + ssv[ri][3];
                 const int m = wave + 8 * ri;
-                for (int j = lane + 256; j < p.ss_n; j += 64)           // more than 256 producing workgroups: the rest, the slow way
-                    t += COH ? __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.ss_in), (m * p.ss_n + j) * 4, 0, 16)) : p.ss_in[m * p.ss_n + j];
+                for (int j = lane + 256; j < p.ss_n; j += 64) t += p.ss_in[m * p.ss_n + j];      // more than 256 producing workgroups: the rest, the slow way
                 ssp[ri] = t;
             }
         }
@@ -337,7 +319,7 @@ struct ImgPhase {
                         }
                     }
                     if (g0 + d == 0) ST_STAMP(3);
-                    if (ig < total) issue<true>(r[d]);
+                    if (ig < total) issue(r[d]);
                     if (g0 + d == total - 1) ST_STAMP(4);
                     if (++cj == spw) { finish_unit(); cj = 0; ++cu; }
                 }
@@ -357,7 +339,7 @@ struct ImgPhase {
                     const int w0 = tid >> 2, rg = tid & 3;
                     float t = am_v[w0 * 4 + rg];
                     if (NT * 256 > 256) t += am_v[(w0 + 4) * 4 + rg];
-                    hst_f32<COH>(reinterpret_cast<char*>(p.ss_out), ((long long)tid * (int)gridDim.x + (int)blockIdx.x) * 4, tid < p.M ? t : 0.f);
+                    st_f32g(reinterpret_cast<char*>(p.ss_out), ((long long)tid * (int)gridDim.x + (int)blockIdx.x) * 4, tid < p.M ? t : 0.f);
                 }
             }
             if (p.am_val) {
@@ -378,8 +360,8 @@ struct ImgPhase {
                     const int i1 = am_i[(w0 + 4) * 4 + rg];
                     if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
                     const long long slot = (long long)tid * (int)gridDim.x + (int)blockIdx.x;
-                    hst_f32<COH>(reinterpret_cast<char*>(p.am_val), slot * 4, b0);
-                    hst_f32<COH>(reinterpret_cast<char*>(p.am_idx), slot * 4, __int_as_float(i0));
+                    st_f32g(reinterpret_cast<char*>(p.am_val), slot * 4, b0);
+                    st_f32g(reinterpret_cast<char*>(p.am_idx), slot * 4, __int_as_float(i0));
                 }
             }
         }

@@ -3,7 +3,7 @@
 // (modeling_qwen2.py:258-299), with a preallocated [layer][B][kv_head][cap][hd] KV cache instead of DynamicCache,
 // and the greedy pick + stop bookkeeping of lm/parallel.py:494-513,599-601 kept on the device.
 #include "common.h"
-#include "decode_chain.h"
+#include "decode_phases.h"
 
 namespace {
 
@@ -198,7 +198,7 @@ extern "C" size_t afhip_llm_workspace_bytes(const afhip_llm_weights* w, int B, i
     tot += align256((size_t)B * w->n_stream * sizeof(int64_t)) + align256((size_t)B * sizeof(int64_t));
     tot += align256((size_t)B * w->hidden * dtype_size(w->dtype)) * 2;
     tot += afhip_masked_argmax_workspace_bytes(B);
-    if (T == 1) tot += align256(afhip_decode_chain_scratch_bytes(w, B));     // decode_chain.hip: barrier words, argmax partials, activation images
+    if (T == 1) tot += align256(afhip_decode_phases_scratch_bytes(w, B));     // decode_phases.hip: argmax partials, sums of squares, activation images
     return tot;
 }
 
@@ -412,45 +412,30 @@ extern "C" int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache*
     int64_t* tok = (int64_t*)(base + off); off += align256((size_t)B * sizeof(int64_t));
     char* emb = base + off; off += align256((size_t)B * H * sz);
     char* hid = base + off; off += align256((size_t)B * H * sz);
-    char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);      // `off` = start of the decode-chain scratch
+    char* am = base + off; off += afhip_masked_argmax_workspace_bytes(B);      // `off` = start of the decode_phases.hip scratch
     int rc;
     AFHIP_CHECK((st->seq_pos == nullptr) == (st->step_counter == nullptr), "afhip_llm_decode_step: seq_pos and step_counter go together");
-    if (w->n_q / w->n_kv <= 32 && afhip_decode_chain_supported(w, B) &&
-        (w->qkv_w8 == nullptr || (w->o_w8 && w->gu_w8 && w->down_w8 && w->qkv_s && w->o_s && w->gu_s && w->down_s && B <= 16))) {
-        // bf16 weights, B <= 16: the GEMMs of the step are the persistent imaged phases of decode_chain.hip -- activations handed from
-        // producer to consumer as fragment-order images -- one launch each (mode 1) or chained behind in-launch grid barriers (mode 2);
-        // the attention launches stay between them and their merge writes the image the o phase reads
+    if (w->n_q / w->n_kv <= 32 && afhip_decode_phases_supported(w, B) &&
+        (w->qkv_w8 == nullptr || (w->o_w8 && w->gu_w8 && w->down_w8 && w->qkv_s && w->o_s && w->gu_s && w->down_s))) {
+        // bf16 model (bf16 or e4m3 weight copies), B <= 16: the GEMMs of the step are the persistent imaged phases of decode_phases.hip --
+        // activations handed from producer to consumer as fragment-order images -- and the attention merge writes the image the o phase reads
         AFHIP_CHECK(pos >= 0 && pos + 1 <= cache->cap && pos + 1 <= w->rope_max_pos && cache->B >= B && cache->k && cache->v,
                     "afhip_llm_decode_step: position %d exceeds the KV capacity %d / rope table %d, or cache batch %d < %d", pos, cache->cap, w->rope_max_pos, cache->B, B);
         AFHIP_CHECK(w->hd == 64 || w->hd == 128, "afhip_llm_decode_step: head_dim %d unsupported", w->hd);
         LlmWs ws = carve(w, B, base, cache->cap);
         char* scratch = base + off;
-        const bool chain = afhip_decode_chain_mode() >= 2 && w->qkv_w8 == nullptr;      // the chained launches take bf16 weights only
-        // the grid-barrier words of the chained launches start every step at zero (one-phase launches have no barrier)
-        if (chain && hipMemsetAsync(scratch, 0, 2048, s) != hipSuccess) { afhip_set_error("decode step: barrier memset failed"); return AFHIP_ERR_LAUNCH; }
-        afhip_chain_step c = {};
-        c.w = w; c.B = B; c.x = ws.x; c.qkv = ws.qkv; c.scratch = scratch; c.st = st; c.step = step; c.bar0 = 0;
-        int rounds = 0;
-        auto launch = [&](int phases, int layer, int qkv_layer) -> int {
-            c.phases = phases; c.layer = layer; c.qkv_layer = qkv_layer;
-            const int r = afhip_decode_chain_launch(c, s, &rounds);
-            c.bar0 += rounds;
-            return r;
-        };
-        ws.att = (char*)afhip_decode_chain_att_image(w, B, scratch);
+        afhip_phase_step c = {};
+        c.w = w; c.B = B; c.x = ws.x; c.qkv = ws.qkv; c.scratch = scratch; c.st = st; c.step = step;
+        auto launch = [&](int phase, int layer) -> int { c.phase = phase; c.layer = layer; return afhip_decode_phase_launch(c, s); };
+        ws.att = (char*)afhip_decode_phases_att_image(w, B, scratch);
         const int L = w->n_layers;
-        if (chain) { if ((rc = launch(AFHIP_PH_EMBED | AFHIP_PH_QKV, 0, 0))) return rc; }
-        else { if ((rc = launch(AFHIP_PH_EMBED, 0, 0)) || (rc = launch(AFHIP_PH_QKV, 0, 0))) return rc; }
+        if ((rc = launch(AFHIP_PH_EMBED, 0))) return rc;
         for (int l = 0; l < L; ++l) {
+            if ((rc = launch(AFHIP_PH_QKV, l))) return rc;
             if ((rc = layer_attention(w, ws, l, B, 1, pos, cache, st->seq_pos, true, s, B <= 8 ? 8 : 16))) return rc;
-            const int tail = l + 1 < L ? AFHIP_PH_QKV : (AFHIP_PH_HEAD | AFHIP_PH_PICK);
-            if (chain) { if ((rc = launch(AFHIP_PH_O | AFHIP_PH_GU | AFHIP_PH_DOWN | tail, l, l + 1))) return rc; }
-            else {
-                if ((rc = launch(AFHIP_PH_O, l, 0)) || (rc = launch(AFHIP_PH_GU, l, 0)) || (rc = launch(AFHIP_PH_DOWN, l, 0))) return rc;
-                if (l + 1 < L) { if ((rc = launch(AFHIP_PH_QKV, l, l + 1))) return rc; }
-                else { if ((rc = launch(AFHIP_PH_HEAD, l, 0)) || (rc = launch(AFHIP_PH_PICK, l, 0))) return rc; }
-            }
+            if ((rc = launch(AFHIP_PH_O, l)) || (rc = launch(AFHIP_PH_GU, l)) || (rc = launch(AFHIP_PH_DOWN, l))) return rc;
         }
+        if ((rc = launch(AFHIP_PH_HEAD, L - 1)) || (rc = launch(AFHIP_PH_PICK, L - 1))) return rc;
         return 0;
     }
     hipLaunchKernelGGL(build_ids_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, (const int64_t*)st->prev_token, ids, B, S);

@@ -1,6 +1,5 @@
-// One weight-streaming GEMM phase of the bf16 decode step (M <= 16 rows, K % 512 == 0): C[M,N] = A'[M,K] . W[N,K]^T, as a device-side
-// object so that it can be a kernel of its own (gemm_stream.hip) or one link of a chain of dependent phases inside ONE launch
-// (decode_chain.hip), where the next phase's weight window is already in flight while the workgroups meet at the grid barrier.
+// One weight-streaming GEMM of the bf16 decode shapes (M <= 16 rows, K % 512 == 0) over a ROW-MAJOR activation: C[M,N] = A'[M,K] . W[N,K]^T,
+// as a device-side object (gemm_stream.hip wraps it in a kernel; img_phase.h is its sibling for activations that arrive as images).
 //
 // What bounds these GEMMs on MI355X is not the weight stream's shape but the ACTIVATION loads next to it
 // (tools/micro/stream_shape.hip: the 136-MB down projection streams at 3.9 TB/s with the activation fragments read from global
@@ -16,9 +15,6 @@
 //               slot (ds_write_b128, two ds_read_b128, no barrier).
 // The eight waves of a workgroup split K (wave w takes steps w, w + 8, ...) and combine through LDS per unit; bias / residual are
 // fetched when a unit starts.  K order per row and the order of the K-slice sum are those of skinny_kernel (gemm_skinny.hip).
-//
-// COH: the activations / residual were written, and the output will be read, by OTHER workgroups of the same launch: those bytes move
-// with sc1 (write-through / L1-bypassing) buffer accesses, the form the grid barrier of decode_chain.hip relies on.
 #pragma once
 #include "skinny.h"
 
@@ -46,29 +42,7 @@ __device__ __forceinline__ int slot_chunk(int RM, int r, int piece) {
     return (piece & 1) * (4 * RM) + (piece >> 1) * RM + (r & 8) + (((r & 7) + piece) & 7);
 }
 
-// hand-off accesses (base is wave-uniform, off < 2^31 bytes)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-template <bool COH> __device__ __forceinline__ u32x4 hld16(const char* base, long long off) {
-    if constexpr (COH) return __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(base), (int)off, 0, 16);
-    else return *reinterpret_cast<const u32x4*>(base + off);
-}
-template <bool COH> __device__ __forceinline__ float hld_bf16(const char* base, long long off) {
-    if constexpr (COH) return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_of(base), (int)off, 0, 16) << 16);
-    else return (float)*reinterpret_cast<const bf16*>(base + off);
-}
-template <bool COH> __device__ __forceinline__ void hst_bf16(char* base, long long off, float v) {
-    const bf16 h = (bf16)v;
-    if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rsrc_of(base), (int)off, 0, 16);
-    else *reinterpret_cast<bf16*>(base + off) = h;
-}
-template <bool COH> __device__ __forceinline__ void hst_f32(char* base, long long off, float v) {
-    if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_of(base), (int)off, 0, 16);
-    else *reinterpret_cast<float*>(base + off) = v;
-}
-
-template <int AMODE, int NT, bool PAIR, bool SLOT, int RM, int DEPTH, bool COH>
+template <int AMODE, int NT, bool PAIR, bool SLOT, int RM, int DEPTH>
 struct StreamPhase {
     static_assert(RM == 8 || RM == 16, "activation image rows");
     static_assert(!PAIR || NT == 2, "SwiGLU pairs: one gate tile + one up tile");
@@ -76,7 +50,6 @@ struct StreamPhase {
     static constexpr int AH = SLOT ? RM / 8 : 1;                   // slot form: coalesced activation loads per step
     static constexpr int NI = (NT * 256 + 511) / 512;               // epilogue items per thread
     static constexpr int SB = 8, NROW = RM / 8;                     // image staging: 16-B chunks per lane per row and batch, rows per wave
-    static constexpr int PRE = DEPTH < 2 ? DEPTH : 2;               // K steps of the window issued before the activations are known to be there
     struct Regs { u32x4 w0[NT], w1[NT], a[AH]; };
 
     // the descriptor, copied field by field into (wave-uniform) registers the compiler cannot re-derive from the kernel-argument segment:
@@ -101,7 +74,6 @@ struct StreamPhase {
     long long aoff[AH];
     int wofs[AH], rofs0, rofs1;
     int ig, iu, ij;
-    int sidx[DEPTH];
     u32x4 sv[NROW][SB], sg[SB];
     float ssq[NROW];
     float ep_b[NI], ep_r[NI];
@@ -154,18 +126,17 @@ struct StreamPhase {
     __device__ __forceinline__ void issue_a(Regs& x, int s) {
         if constexpr (SLOT) {
 #pragma unroll
-            for (int h = 0; h < AH; ++h) x.a[h] = hld16<COH>(p.A, aoff[h] + (long long)s * (KS * 2));
+            for (int h = 0; h < AH; ++h) x.a[h] = ld16(p.A + aoff[h] + (long long)s * (KS * 2));
         }
     }
-    template <bool WITH_A> __device__ __forceinline__ int issue(Regs& x) {
+    __device__ __forceinline__ void issue(Regs& x) {
         const int s = wave + NW * ij;
         const long long koff = (long long)s * (KS * 2) + q * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
-        if constexpr (WITH_A) issue_a(x, s);
+        issue_a(x, s);
         ++ig;
         if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
-        return s;
     }
     __device__ __forceinline__ void stage_load(int c0) {
         const int nch = p.K >> 3;
@@ -176,7 +147,7 @@ struct StreamPhase {
 #pragma unroll
             for (int ri = 0; ri < NROW; ++ri) {
                 const int m = wave + 8 * ri < p.M ? wave + 8 * ri : p.M - 1;
-                sv[ri][j] = hld16<COH>(p.A, (long long)m * p.lda * 2 + cc * 16);
+                sv[ri][j] = ld16(p.A + (long long)m * p.lda * 2 + cc * 16);
             }
             if constexpr (AMODE == SKINNY_A_RMSNORM) sg[j] = ld16(p.norm_w + cc * 16);
         }
@@ -209,7 +180,6 @@ struct StreamPhase {
     }
     // bias / residual of this thread's epilogue items (o = tid (+ 512): reg = o & 3, column = (o >> 2) & 15, row group = (o >> 6) & 3,
     // tile = o >> 8) are fetched when a unit STARTS: behind the combine barrier their L2 / HBM round trip would end every unit.
-    // (Chained phases: the residual a thread adds is the element it wrote itself in an earlier phase.)
     __device__ __forceinline__ void fetch_epi(int ui) {
         if constexpr (!PAIR) {
             const int u = (int)blockIdx.x + ui * (int)gridDim.x;
@@ -221,14 +191,13 @@ struct StreamPhase {
                 const bool ok = o < NT * 256 && (ln & 15) < TR && n < p.N && m < p.M;
                 const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional (no branch, no drain per element)
                 ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
-                ep_r[i] = p.res ? hld_bf16<COH>(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
+                ep_r[i] = p.res ? (float)*reinterpret_cast<const bf16*>(p.res + ((long long)mc * p.ldres + nc) * 2) : 0.f;
             }
         }
     }
 
-    // Indices, the first weight window (and, when the activations are already there, the first loads of the image / the slots).
-    // A_READY = false: the activations are still being written by other workgroups -- only weights (and own-data residuals) move.
-    template <bool A_READY> __device__ __forceinline__ void begin() {
+    // Indices, the first loads of the image (issued before the weight window: vmcnt retires in order), the window, the first epilogue operands.
+    __device__ __forceinline__ void begin() {
         tid = threadIdx.x; lane = tid & 63; wave = tid >> 6;
         c16 = lane & 15; q = lane >> 4;
         TR = p.tile_rows;
@@ -258,15 +227,11 @@ struct StreamPhase {
         for (int ri = 0; ri < NROW; ++ri) ssq[ri] = 0.f;
         ig = 0; iu = 0; ij = 0;
         // the staging loads go out BEFORE the weight window (vmcnt retires in order: behind the weights they would wait for HBM)
-        if constexpr (!SLOT && A_READY) stage_load(0);
+        if constexpr (!SLOT) stage_load(0);
         if (my_units > 0) set_rows(0);
-        // A_READY: the whole window.  Otherwise PRE steps only: the activation loads that follow the grid barrier retire in order
-        // BEHIND whatever is issued here, so a full window in front of them would hold the image back until all of it has landed
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            sidx[d] = 0;
-            if ((A_READY || d < PRE) && ig < total) sidx[d] = issue<A_READY>(r[d]);
-        }
+        for (int d = 0; d < DEPTH; ++d)
+            if (ig < total) issue(r[d]);
         ST_STAMP(1);
         if (my_units > 0) fetch_epi(0);
     }
@@ -296,7 +261,7 @@ struct StreamPhase {
                         const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.norm_eps);
                         g *= rs; uu *= rs;
                     }
-                    hst_bf16<COH>(p.C, ((long long)mrow * p.ldc + gi) * 2, silu(g) * uu);
+                    reinterpret_cast<bf16*>(p.C)[(long long)mrow * p.ldc + gi] = (bf16)(silu(g) * uu);
                 }
             }
         } else {
@@ -314,8 +279,8 @@ struct StreamPhase {
                         if (p.bias) v += ep_b[i];
                         if (p.res) v += ep_r[i];
                         if (p.C) {
-                            if (p.out_f32) hst_f32<COH>(p.C, ((long long)mm * p.ldc + nn) * 4, v);
-                            else hst_bf16<COH>(p.C, ((long long)mm * p.ldc + nn) * 2, v);
+                            if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)mm * p.ldc + nn] = v;
+                            else reinterpret_cast<bf16*>(p.C)[(long long)mm * p.ldc + nn] = (bf16)v;
                         }
                         if (p.am_val) {
                             bool ok = false;
@@ -331,26 +296,15 @@ struct StreamPhase {
     }
 
     // The activations are there: image / slot loads, the K loop over all units, the epilogues.
-    template <bool A_READY> __device__ __forceinline__ void run() {
-        if constexpr (SLOT && !A_READY) {
-#pragma unroll
-            for (int d = 0; d < PRE; ++d)
-                if (d < total) issue_a(r[d], sidx[d]);
-        }
-        if constexpr (!SLOT && !A_READY) stage_load(0);
-        if constexpr (!A_READY) {
-#pragma unroll
-            for (int d = PRE; d < DEPTH; ++d)
-                if (ig < total) issue<true>(r[d]);
-        }
+    __device__ __forceinline__ void run() {
         if constexpr (!SLOT) {
             const int nch = p.K >> 3;
 #ifdef AFHIP_STREAM_STAMPS
-            if (!COH) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH * 2 * NT) : "memory"); ST_STAMP(6); }   // standalone: the staging loads (issued first) have landed
+            { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH * 2 * NT) : "memory"); ST_STAMP(6); }   // the staging loads (issued first) have landed
 #endif
             stage_store(0);
 #ifdef AFHIP_STREAM_STAMPS
-            if (!COH) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ST_STAMP(7); }
+            { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ST_STAMP(7); }
 #endif
             for (int c0 = 64 * SB; c0 < nch; c0 += 64 * SB) { stage_load(c0); stage_store(c0); }
             if constexpr (AMODE == SKINNY_A_RMSNORM) {
@@ -390,7 +344,7 @@ struct StreamPhase {
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, r[d].w1[t]), acc[t], 0, 0, 0);
                     }
                     if (g0 + d == 0) ST_STAMP(3);
-                    if (ig < total) issue<true>(r[d]);
+                    if (ig < total) issue(r[d]);
                     if (g0 + d == total - 1) ST_STAMP(4);
                     if (++cj == spw) { finish_unit(); cj = 0; ++cu; }
                 }
@@ -418,8 +372,8 @@ struct StreamPhase {
                     const int i1 = am_i[(w0 + 4) * 4 + rg];
                     if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
                     const long long slot = (long long)tid * (int)gridDim.x + (int)blockIdx.x;
-                    hst_f32<COH>(reinterpret_cast<char*>(p.am_val), slot * 4, b0);
-                    hst_f32<COH>(reinterpret_cast<char*>(p.am_idx), slot * 4, __int_as_float(i0));
+                    p.am_val[slot] = b0;
+                    p.am_idx[slot] = i0;
                 }
             }
         }

@@ -38,7 +38,7 @@ _lib_def.define("llm_forward_ragged(Tensor weights, Tensor x, Tensor seq_pos, in
 _lib_def.define("lm_head(Tensor weights, Tensor hidden_rows, int n_stream, Tensor(a!) workspace) -> Tensor")
 _lib_def.define("llm_decode_step(Tensor weights, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor(c!) prev_token, Tensor(d!) out_tokens, Tensor(e!) finished_at, "
                 "Tensor allowed, int eos_id, int eot_id, Tensor(f!) seq_pos, Tensor(g!) step_counter, int max_pos, Tensor(h!) workspace, "
-                "int head_rows, Tensor(i!) status) -> ()")
+                "int head_rows) -> ()")
 
 _fe = None
 
@@ -183,13 +183,13 @@ def _lm_head_meta(weights, hidden_rows, n_stream, workspace):
 
 
 def _llm_decode_step(weights, k_cache, v_cache, prev_token, out_tokens, finished_at, allowed, eos_id, eot_id, seq_pos, step_counter, max_pos, workspace,
-                     head_rows, status):
+                     head_rows):
     lib = L.lib()
     st = L.DecodeState()
     st.prev_token, st.out_tokens, st.finished_at = prev_token.data_ptr(), out_tokens.data_ptr(), finished_at.data_ptr()
     st.allowed, st.n_iv, st.eos_id, st.eot_id = allowed.data_ptr(), allowed.shape[0], eos_id, eot_id
     st.seq_pos, st.step_counter = seq_pos.data_ptr(), step_counter.data_ptr()
-    st.head_rows, st.status = head_rows, status.data_ptr()
+    st.head_rows = head_rows
     cs = _kv(k_cache, v_cache)
     L.check(lib.afhip_llm_decode_step(_struct(weights, L.LlmWeights), C.byref(cs), C.byref(st), prev_token.shape[0], max_pos, 0,
                                       L.ptr(workspace), workspace.numel(), L.stream_ptr()))

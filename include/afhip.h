@@ -429,9 +429,6 @@ typedef struct {
     /* > 0: every id inside `allowed` is below head_rows, so the step may compute logits for lm_head rows [0, head_rows) only (text decode:
      * 256 + text vocab of the 160 520 rows, lm/parallel.py:557-568).  0 = all rows. */
     int head_rows;
-    /* Optional [1] int32 (device), zeroed by the caller: set to 1 if a step's in-launch grid barrier (decode_chain.hip) timed out --
-     * the tokens of that step are then undefined.  NULL = not reported. */
-    int32_t* status;
 } afhip_decode_state;
 int afhip_llm_decode_step(const afhip_llm_weights* w, afhip_kv_cache* cache, afhip_decode_state* st, int B, int pos,
                           int step, void* workspace, size_t workspace_bytes, void* stream);

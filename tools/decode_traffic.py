@@ -11,8 +11,8 @@ import json
 import re
 import sys
 
-# the kernels of the decode step (AFHIP_DECODE_CHAIN 1 / 2); rmsnorm / gemm_pp / rope launches in the same trace belong to the prefill
-STEP_KERNELS = ("img_phase_kernel", "attn_kernel", "attn_combine_kernel", "embed_kernel", "pick_kernel", "decode_chain_kernel")
+# the kernels of the decode step; rmsnorm / gemm_pp / rope launches in the same trace belong to the prefill
+STEP_KERNELS = ("img_phase_kernel", "attn_kernel", "attn_combine_kernel", "embed_kernel", "pick_kernel")
 
 
 def short(name):

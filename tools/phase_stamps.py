@@ -1,7 +1,7 @@
-"""Diagnostic build of the decode chain (decode_chain.hip + stream_phase.h) with 100-MHz wall-clock stamps of wave 0 of every workgroup --
-never the product library.  For one layer's launch (o -> gate/up -> down -> q|k|v): per phase, when the weight window was issued, when the
-grid barrier in front of it was passed, when its image was staged, first / last K step consumed, end of its K loop, arrival at the next barrier.
-usage: python tools/chain_stamps.py [B] [layer]"""
+"""Diagnostic build of the decode step's GEMM phases (decode_phases.hip + img_phase.h) with 100-MHz wall-clock stamps of wave 0 of every
+workgroup -- never the product library.  For the launches of one layer (q|k|v, o, gate/up, down; the stamps share one clock, so the gaps
+BETWEEN the launches show too): when a launch starts, when its weight window has been issued, first / last K step consumed, end of its K loop.
+usage: python tools/phase_stamps.py [B] [layer]"""
 import glob
 import os
 import subprocess
@@ -15,12 +15,12 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "audio-intelligence_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DAFHIP_STREAM_STAMPS"]
 objs = []
-for name in ("gemm_stream", "gemm_skinny", "decode_chain"):   # every unit that sees SkinnyP / ImgDesc
+for name in ("gemm_stream", "gemm_skinny", "decode_phases"):   # every unit that sees SkinnyP / ImgDesc
     obj = f"/tmp/{name}_stamps.o"
     subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj], check=True)
     objs.append(obj)
-lib = "/tmp/libafhip_chainstamps.so"
-skip = ("gemm_stream.o", "gemm_skinny.o", "decode_chain.o")
+lib = "/tmp/libafhip_phasestamps.so"
+skip = ("gemm_stream.o", "gemm_skinny.o", "decode_phases.o")
 others = [o for o in glob.glob(os.path.join(CSRC, "*.o")) if os.path.basename(o) not in skip]
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + others, check=True)
 from audio_intelligence_amd import _lib as L  # noqa: E402
@@ -42,15 +42,15 @@ hid, cache = model._forward_hidden(x, model.new_cache(B, ctx + 200))
 tok = model.text_token.expand(B, -1, -1).clone()
 buf = torch.zeros(5 * 256 * 8, dtype=torch.int64, device=dev)
 os.environ["AFHIP_STREAM_DBGPTR"] = hex(buf.data_ptr())
-os.environ["AFHIP_CHAIN_STAMP_LAYER"] = str(layer)
+os.environ["AFHIP_PHASE_STAMP_LAYER"] = str(layer)
 cache.length = ctx
 hyp, _, cache = model._greedy_device_loop(tok, cache, "text", 40, poll=10 ** 9)     # graph replays: the stamps of the last step survive
 torch.cuda.synchronize()
 t = buf.cpu().reshape(5, 256, 8).double()
 base = float(t[0][:, 0][t[0][:, 0] > 0].min())
-names = ["phase begin", "window issued", "image staged", "first step consumed", "last step consumed", "K loop end", "barrier passed", "arrived"]
-order = [0, 1, 6, 2, 3, 4, 5, 7]
-for pi, pname in enumerate(["o", "gate/up", "down", "q|k|v (next layer)", "head"]):
+names = ["launch begin", "window issued", "K loop about to start", "first step consumed", "last step consumed", "K loop end"]
+order = [0, 1, 2, 3, 4, 5]
+for pi, pname in enumerate(["o", "gate/up", "down", "q|k|v", "head"]):
     tt = t[pi]
     if float(tt.max()) == 0:
         continue
