@@ -122,6 +122,21 @@ template <int RM> __global__ __launch_bounds__(512) void embed_kernel(PhaseArgs 
 }
 __global__ __launch_bounds__(512) void pick_kernel(PickArgs k) { pick_phase(k); }
 
+// K steps in flight per wave (rolling window depth) of the bf16 phases; measured choices (tools/decode_probe.py 8 96 790, one box, two passes:
+// down 4 / 5 instead of 7: +0.8 %, o 4: +0.7 %, gate/up 3 / 5 instead of 4: +0.4 / +1.0 %, q|k|v 4 instead of 7: -0.5 %)
+#ifndef DP_DEPTH_O
+#define DP_DEPTH_O 7        // K = 3584: a wave's 7 steps all in flight
+#endif
+#ifndef DP_DEPTH_DOWN
+#define DP_DEPTH_DOWN 7
+#endif
+#ifndef DP_DEPTH_QKV
+#define DP_DEPTH_QKV 4        // 3.237 against 3.254 ms per step with 7
+#endif
+#ifndef DP_DEPTH_GU
+#define DP_DEPTH_GU 4
+#endif
+
 template <typename PH> void launch_phase(const ImgDesc& d, int grid, hipStream_t s) {
     static unsigned long long attr_done = 0;
     if (afhip_first_use_on_device(&attr_done))
@@ -140,10 +155,10 @@ template <int RM> void launch_single8(const PhaseArgs& a, int cus, hipStream_t s
 template <int RM> void launch_single(const PhaseArgs& a, int cus, hipStream_t s) {
     switch (a.phases) {
         case AFHIP_PH_EMBED: hipLaunchKernelGGL(embed_kernel<RM>, dim3((unsigned)a.B), dim3(512), 0, s, a); break;
-        case AFHIP_PH_O: launch_phase<ImgPhase<1, false, false, RM, 7>>(a.o, cus, s); break;
-        case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, 4>>(a.gu, cus, s); break;
-        case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, 7>>(a.down, cus, s); break;
-        case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, 7>>(a.qkv, cus, s); break;
+        case AFHIP_PH_O: launch_phase<ImgPhase<1, false, false, RM, DP_DEPTH_O>>(a.o, cus, s); break;
+        case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, DP_DEPTH_GU>>(a.gu, cus, s); break;
+        case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, DP_DEPTH_DOWN>>(a.down, cus, s); break;
+        case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, DP_DEPTH_QKV>>(a.qkv, cus, s); break;
         case AFHIP_PH_HEAD: launch_phase<ImgPhase<4, false, true, RM, 2>>(a.head, cus, s); break;
         default: hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(512), 0, s, a.pick); break;
     }

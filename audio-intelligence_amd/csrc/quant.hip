@@ -199,20 +199,26 @@ void launch_wave_form(const bf16* x, long long ld_x, const bf16* w, const bf16* 
 
 }  // namespace
 
-// max |x| of a bf16 buffer (calibration of static activation scales): 16 B per lane per step, wave max, one atomic per wave
+// max |x| of a bf16 buffer (calibration of static activation scales): 16 B per lane per step, wave max, one atomic per wave.  The maximum is
+// taken over the BIT PATTERNS of |x| (sign cleared): non-negative floats order like their patterns, and an infinity or a NaN has a larger
+// pattern than every finite value, so a non-finite activation comes out as a non-finite maximum instead of being dropped (fmaxf ignores NaN).
 __global__ __launch_bounds__(256) void absmax_bf16_kernel(const u32x4* __restrict__ x, long long n16, unsigned* __restrict__ out) {
-    float m = 0.f;
+    unsigned m = 0u;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
         const u32x4 v = x[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            m = fmaxf(m, fabsf(__uint_as_float(v[e] << 16)));
-            m = fmaxf(m, fabsf(__uint_as_float(v[e] & 0xffff0000u)));
+            const unsigned lo = (v[e] << 16) & 0x7fffffffu, hi = v[e] & 0x7fff0000u;
+            m = lo > m ? lo : m;
+            m = hi > m ? hi : m;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 extern "C" int afhip_absmax_bf16(const void* x, long long n, float* out, void* stream) {

@@ -120,13 +120,38 @@ class AFWhisperEncoder(nn.Module):
         return self
 
     @torch.no_grad()
-    def calibrate_fp8(self, mel_btc: torch.Tensor, feat_len: Optional[torch.Tensor] = None, margin: float = 2.0, attention_output: bool = True):
-        """Static quantisation of fc2's input (afhip_encoder_weights.fc2_in_scale).  Runs the e4m3 forward once on `mel_btc` with the
-        GELU output still in bf16 and records max |value| per layer on the device; scale_l = margin * amax_l / 448 (e4m3's relative
-        precision does not depend on the scale, so the margin only costs range at the small end; larger values saturate at 448).  From
-        then on fc1 writes that activation as e4m3 bytes and fc2 reads them with scale_l for every row: the [rows, ffn] bf16 round trip
-        and the per-row quantisation launch are gone.  `attention_output=True` does the same for the attention output -> out-projection
-        (the encoder attention kernel writes e4m3).  Returns the fc2 scales.  `calibrate_fp8(None)` drops everything again."""
+    def _collect_amax(self, batches) -> torch.Tensor:
+        """max |GELU output| ([0, L)) and max |attention output| ([L, 2 L)) per layer over `batches` (one mel tensor, a (mel, feat_len) pair
+        or a list of either), from forwards that keep those activations in bf16.  The device maxima accumulate across the forwards
+        (afhip_absmax_bf16 merges with an atomic max); a non-finite activation comes back as a non-finite maximum."""
+        if torch.is_tensor(batches) or (isinstance(batches, tuple) and len(batches) == 2 and torch.is_tensor(batches[0])):
+            batches = [batches]
+        nl = self.config.encoder_layers
+        keep = (self._fc2_in_scale, self._att_out_scale)
+        self._fc2_in_scale, self._att_out_scale = None, None
+        self._calib = torch.zeros(2 * nl, dtype=torch.float32, device=self.device)
+        self._packed = None
+        try:
+            for item in batches:
+                mel, flen = item if isinstance(item, tuple) else (item, None)
+                self.encode_btc(mel, flen)
+            torch.cuda.synchronize(self.device)
+            return self._calib.cpu()
+        finally:
+            self._calib = None
+            self._fc2_in_scale, self._att_out_scale = keep
+            self._packed = None
+
+    def calibrate_fp8(self, mel_btc, feat_len: Optional[torch.Tensor] = None, margin: float = 2.0, attention_output: bool = True):
+        """Static quantisation of fc2's input (afhip_encoder_weights.fc2_in_scale).  Runs the e4m3 forward on `mel_btc` (one batch, or a list
+        of mel tensors / (mel, feat_len) pairs: the maxima accumulate over all of them) with the GELU output still in bf16 and records
+        max |value| per layer on the device; scale_l = margin * amax_l / 448 (e4m3's relative precision does not depend on the scale, so
+        the margin only costs range at the small end; larger values saturate at 448 -- `check_fp8_range` tells whether a batch would).
+        From then on fc1 writes that activation as e4m3 bytes and fc2 reads them with scale_l for every row: the [rows, ffn] bf16 round
+        trip and the per-row quantisation launch are gone.  `attention_output=True` does the same for the attention output ->
+        out-projection (the encoder attention kernel writes e4m3).  Returns the fc2 scales.  `calibrate_fp8(None)` drops everything again.
+        No reference counterpart: the evidence for this mode is a token-level contract on seeded synthetic weights, not a
+        fixture of the reference."""
         if mel_btc is None:
             self._fc2_in_scale, self._att_out_scale, self._packed = None, None, None
             return None
@@ -134,20 +159,33 @@ class AFWhisperEncoder(nn.Module):
             raise L.AfhipError("calibrate_fp8: call enable_fp8() first")
         self._fc2_in_scale, self._att_out_scale = None, None
         nl = self.config.encoder_layers
-        self._calib = torch.zeros(2 * nl, dtype=torch.float32, device=self.device)      # [0, nl): max |GELU output|; [nl, 2 nl): max |attention output|
-        self._packed = None
-        self.encode_btc(mel_btc, feat_len)
-        torch.cuda.synchronize(self.device)
-        amax = self._calib.cpu()
-        self._calib = None
+        amax = self._collect_amax((mel_btc, feat_len) if torch.is_tensor(mel_btc) else mel_btc)
         if not bool(torch.isfinite(amax).all()) or float(amax[:nl].min()) <= 0.0:
-            self._packed = None
-            raise L.AfhipError(f"calibrate_fp8: unusable activation maxima {amax.tolist()}")
+            raise L.AfhipError(f"calibrate_fp8: unusable activation maxima (non-finite activations, or a layer that is all zero) {amax.tolist()}")
         self._fc2_in_scale = (amax[:nl] * (margin / 448.0)).to(torch.float32).contiguous()
         if attention_output and float(amax[nl:].min()) > 0.0:
             self._att_out_scale = (amax[nl:] * (margin / 448.0)).to(torch.float32).contiguous()
         self._packed = None
         return self._fc2_in_scale.clone()
+
+    def check_fp8_range(self, mel_btc, feat_len: Optional[torch.Tensor] = None, raise_on_saturation: bool = True) -> torch.Tensor:
+        """Would `mel_btc` saturate the statically quantised activations?  Re-measures the per-layer maxima on it (bf16 activations, the
+        calibration forward) and returns max |value| / (448 * scale) per quantised tensor ([0, L): fc2 input, [L, 2 L): attention output,
+        NaN where that tensor is not statically quantised): above 1 the e4m3 epilogues clip at 448 silently.  Raises by default."""
+        if self._fc2_in_scale is None:
+            raise L.AfhipError("check_fp8_range: no static scales (calibrate_fp8 first)")
+        nl = self.config.encoder_layers
+        amax = self._collect_amax((mel_btc, feat_len) if torch.is_tensor(mel_btc) else mel_btc)
+        lim = torch.full((2 * nl,), float("nan"))
+        lim[:nl] = self._fc2_in_scale * 448.0
+        if self._att_out_scale is not None:
+            lim[nl:] = self._att_out_scale * 448.0
+        ratio = amax / lim
+        bad = (~torch.isfinite(amax)) | (ratio > 1.0)
+        if raise_on_saturation and bool(bad.any()):
+            raise L.AfhipError(f"check_fp8_range: activations exceed the calibrated e4m3 range (max / limit per tensor: {ratio.tolist()}): "
+                               "re-calibrate on representative audio or use the per-row dynamic mode (calibrate_fp8(None))")
+        return ratio
 
     # ---------------------------------------------------------------- checkpoints
     @classmethod

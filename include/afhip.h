@@ -160,7 +160,8 @@ int afhip_rmsnorm(const void* x, const void* w, void* y, int rows, int D, float 
 int afhip_quant_rows(const void* x, int ld_x, const void* w, const void* b, float eps, int mode, void* q, float* scale,
                      int rows, int D, void* stream);
 /* Calibration helper for statically quantised activations (afhip_encoder_weights.fc2_in_scale): max |x| over n bf16 values
- * (n % 8 == 0, x 16-byte aligned), merged into *out with an atomic max on the float's bit pattern -- the caller zeroes *out. */
+ * (n % 8 == 0, x 16-byte aligned), merged into *out with an atomic max on the float's bit pattern -- the caller zeroes *out.
+ * An infinity or a NaN in x comes out as inf / NaN (their patterns order above every finite value): the caller's isfinite() check sees it. */
 int afhip_absmax_bf16(const void* x, long long n, float* out, void* stream);
 int afhip_ln_stats_finalize(const float* partials, int P, int rows, int D, float eps, float* stats, void* stream);
 int afhip_row_stats(const void* x, int rows, int D, float eps, int dtype, float* stats, void* stream);

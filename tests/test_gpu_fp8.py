@@ -232,6 +232,13 @@ def test_absmax_bf16_and_calibration_scales():
     L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xd.data_ptr()), C.c_longlong(xd.numel()), C.c_void_p(out.data_ptr()), L.stream_ptr()))
     torch.cuda.synchronize()
     assert float(out[0]) == 77.5
+    xi = x.clone(); xi[2, 99] = float("-inf")
+    out.zero_()
+    L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xi.to(DEV).data_ptr()), C.c_longlong(xi.numel()), C.c_void_p(out.data_ptr()), L.stream_ptr()))
+    assert float(out[0]) == float("inf")                           # non-finite values are reported, not skipped ...
+    xi[0, 3] = float("nan")
+    L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xi.to(DEV).data_ptr()), C.c_longlong(xi.numel()), C.c_void_p(out.data_ptr()), L.stream_ptr()))
+    assert bool(torch.isnan(out[0]))                               # ... and a NaN outranks everything
     with pytest.raises(L.AfhipError):
         L.check(L.lib().afhip_absmax_bf16(C.c_void_p(xd.data_ptr()), C.c_longlong(12), C.c_void_p(out.data_ptr()), L.stream_ptr()))
     from audio_intelligence_amd.multimodal_io.modeling_whisper import AFWhisperEncoder, AFWhisperEncoderConfig
@@ -255,5 +262,25 @@ def test_absmax_bf16_and_calibration_scales():
     assert not torch.equal(stat, base)                             # the static path is really taken
     rel = float((stat.float() - base.float()).pow(2).mean().sqrt() / base.float().pow(2).mean().sqrt())
     assert rel < 0.1, rel                                          # and stays an e4m3-sized perturbation of the dynamic mode
+    # several calibration batches accumulate: the louder clip sets the maxima, the order does not matter
+    loud = (mel.float() * 1.5).to(torch.bfloat16)
+    s_both = enc.calibrate_fp8([mel, (loud, None)], margin=2.0)
+    s_loud = enc.calibrate_fp8(loud, margin=2.0)
+    assert torch.equal(s_both, torch.maximum(s1, s_loud)) and torch.equal(enc.calibrate_fp8([loud, mel], margin=2.0), s_both)
+    # the range check: calibrated on `mel` with no margin, the clip itself just fits (ratio <= 1), the louder one does not
+    enc.calibrate_fp8(mel, margin=1.001)
+    scales_before = (enc._fc2_in_scale.clone(), enc._att_out_scale.clone())
+    r = enc.check_fp8_range(mel)
+    assert r.shape == (4,) and float(r.max()) <= 1.0 and float(r.min()) > 0.9, r
+    r2 = enc.check_fp8_range(loud, raise_on_saturation=False)
+    if float(r2.max()) > 1.0:
+        with pytest.raises(L.AfhipError, match="exceed the calibrated e4m3 range"):
+            enc.check_fp8_range(loud)
+    assert torch.equal(enc._fc2_in_scale, scales_before[0]) and torch.equal(enc._att_out_scale, scales_before[1])     # a check changes nothing
+    # a non-finite activation is reported, not dropped: the maximum is taken over bit patterns, NaN / inf order above every finite value
+    bad = mel.clone()
+    bad[0, 5, 7] = float("nan")
+    with pytest.raises(L.AfhipError, match="unusable activation maxima"):
+        enc.calibrate_fp8(bad)
     assert enc.calibrate_fp8(None) is None and enc._fc2_in_scale is None and enc._att_out_scale is None
     assert torch.equal(enc.encode_btc(mel), base)                  # scales dropped: back to the dynamic mode, bit for bit

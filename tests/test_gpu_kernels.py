@@ -576,7 +576,7 @@ def test_gemm_layernorm_folded_forms():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nq,nkv,hd,tk", [(28, 4, 128, 801), (12, 2, 64, 300), (8, 8, 64, 65), (12, 2, 64, 1)])
+@pytest.mark.parametrize("nq,nkv,hd,tk", [(28, 4, 128, 801), (28, 4, 128, 890), (12, 2, 64, 300), (8, 8, 64, 65), (12, 2, 64, 1)])
 def test_attention_decode_fused_rope_append_is_bit_identical(dt, nq, nkv, hd, tk):
     """Decode attention with RoPE + KV append folded into the launch (afhip_attn_args.new_k) against the two-launch form
     (afhip_rope_kv, then afhip_attention): outputs AND the cache rows written must be bit-identical in both dtypes."""
