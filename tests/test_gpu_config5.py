@@ -266,6 +266,48 @@ def test_llm_7b_full_depth_properties(mode):
     print(f"28 layers, B=8, T={T}+{n_dec} ({mode}): finite, ids in the allowed set, batch-invariant, reproducible; first ids {toks[0].tolist()[:8]}")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "w8a16"])
+@pytest.mark.parametrize("B", [5, 11])
+def test_llm_7b_decode_odd_batch_long_context(mode, B):
+    """The imaged decode step (decode_phases.hip) away from the benchmark's shape: an ODD batch (5: 8-row activation images with three empty
+    rows; 11: 16-row images) at a context of 2300 positions -- 18 key ranges of 128, the merge's general path (more than 16 ranges) writing the
+    o-projection's image -- decoding across 2304 = 18 x 128, so the number of live ranges grows inside the replayed graph.  A sequence decoded
+    alone gives the same bits as inside the batch, a second run reproduces the first, the cache behind the context stays untouched."""
+    _need_gpu()
+    T, n_dec = 2300, 8
+    model, cfg, vocab, iv = _build_7b_on_device(2)
+    if mode == "w8a16":
+        model.enable_fp8_decode(True)
+    model.eos_token_id = model.eot_token_id = -1
+    g = torch.Generator(device=DEV).manual_seed(50 + B)
+    x = (torch.randn((B, T, cfg["hidden_size"]), generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+
+    def run(sel):
+        cache = model.new_cache(len(sel), T + n_dec + 8)
+        cache.k.fill_(7.0)
+        cache.v.fill_(7.0)
+        hid, cache = model._forward_hidden(x[sel].contiguous(), cache)
+        tok = model.text_token.expand(len(sel), -1, -1).clone()
+        hyp, _, cache = model._greedy_device_loop(tok, cache, "text", n_dec, poll=10 ** 9)
+        return hid, hyp[:, :, 0], cache
+
+    hid, toks, cache = run(list(range(B)))
+    assert bool(torch.isfinite(hid).all())
+    ts, te = iv["text"][0]
+    t = toks.cpu()
+    assert bool((((t >= ts) & (t < te)) | (t == 2) | (t == 3)).all()), t
+    used = cache.length
+    assert used == T + n_dec
+    assert bool((cache.k[:, :, :, used:] == 7.0).all()) and bool((cache.v[:, :, :, used:] == 7.0).all()), "KV cache written behind the context"
+    assert bool(torch.isfinite(cache.k[:, :, :, :used].float()).all())
+    hid2, toks2, _ = run(list(range(B)))
+    assert torch.equal(hid, hid2) and torch.equal(toks, toks2), "not reproducible"
+    for b in (0, B // 2, B - 1):
+        h1, t1, _ = run([b])
+        assert torch.equal(h1[0], hid[b]), f"sequence {b}: prefill differs between B=1 and B={B}"
+        assert t1[0].tolist() == toks[b].tolist(), f"{mode} sequence {b}: B=1 ids {t1[0].tolist()} != batched {toks[b].tolist()}"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # fp8 encoder mode: the token-level contract (SURVEY 8d config 5)
 def _fp8_encoder_pipeline():
