@@ -136,6 +136,19 @@ __global__ __launch_bounds__(512) void pick_kernel(PickArgs k) { pick_phase(k); 
 #ifndef DP_DEPTH_GU
 #define DP_DEPTH_GU 4
 #endif
+// ... and of the e4m3-weight phases (a K step is 128 elements there)
+#ifndef DP8_DEPTH_O
+#define DP8_DEPTH_O 7
+#endif
+#ifndef DP8_DEPTH_DOWN
+#define DP8_DEPTH_DOWN 7
+#endif
+#ifndef DP8_DEPTH_QKV
+#define DP8_DEPTH_QKV 4
+#endif
+#ifndef DP8_DEPTH_GU
+#define DP8_DEPTH_GU 3       // 2.264-2.272 against 2.268-2.287 ms per step with 4 (three passes, one box); 2: 2.281-2.297
+#endif
 
 template <typename PH> void launch_phase(const ImgDesc& d, int grid, hipStream_t s) {
     static unsigned long long attr_done = 0;
@@ -145,10 +158,10 @@ template <typename PH> void launch_phase(const ImgDesc& d, int grid, hipStream_t
 }
 template <int RM> void launch_single8(const PhaseArgs& a, int cus, hipStream_t s) {      // e4m3 weights (W8A16)
     switch (a.phases) {
-        case AFHIP_PH_O: launch_phase<ImgPhase<1, false, false, RM, 7, true>>(a.o, cus, s); break;
-        case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, 4, true>>(a.gu, cus, s); break;
-        case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, 7, true>>(a.down, cus, s); break;
-        case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, 4, true>>(a.qkv, cus, s); break;
+        case AFHIP_PH_O: launch_phase<ImgPhase<1, false, false, RM, DP8_DEPTH_O, true>>(a.o, cus, s); break;
+        case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, DP8_DEPTH_GU, true>>(a.gu, cus, s); break;
+        case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, DP8_DEPTH_DOWN, true>>(a.down, cus, s); break;
+        case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, DP8_DEPTH_QKV, true>>(a.qkv, cus, s); break;
         default: launch_phase<ImgPhase<4, false, true, RM, 2, true>>(a.head, cus, s); break;
     }
 }
