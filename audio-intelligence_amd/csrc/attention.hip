@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int qrow_c = qrow < Tq ? qrow : Tq - 1;
     const int qpos = p.q_pos0 + qrow;
     const int wave_qpos_min = p.q_pos0 + q0 + wave * 32;   // smallest query position held by this wave
+    const bool wave_live = q0 + wave * 32 < Tq;            // wave-uniform
 
     const char* qb = p.q + (q_off + (long long)hq * p.q_hs) * SZ;
     const char* kb = p.k + (kv_off + (long long)hkv * p.kv_hs) * SZ;
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         Vt = Ks + KT * KROWB;
         if (t + 1 < ntiles) load_tile(t + 1);
 
+        // a wave whose 32 query rows all lie past the sequence (decode: the GQA group's few rows live in wave 0 alone) only helps with the tile
+        // loads and the barriers: its S / softmax / PV would be thrown away and its fragment reads compete for the LDS with the live wave's
+        if (wave_live) {
         // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
         f32x16 st[2];
 #pragma unroll
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
 
+        }   // wave_live
         AT_STAMP(3);
         if constexpr (NBUF == 2) {
             if (t + 1 < ntiles) store_tile(cur ^ 1);   // the other stage: its last readers passed the previous barrier
