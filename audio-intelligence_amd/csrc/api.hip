@@ -41,6 +41,7 @@ const OptDef kOpts[AFHIP_OPT_COUNT] = {
     {"DECODE_IMAGED", 1},           // decode step GEMMs: 1 = persistent imaged phases (decode_phases.hip), 0 = the round-3 launches over row-major activations
     {"DECODE_MERGE", 0},            // split-context decode attention: merge by the last-arriving workgroup inside the launch
     {"DECODE_KEY_SPLIT", 0},        // keys per workgroup of the split-context decode attention (0 = the built-in 128)
+    {"DECODE_LEAN", 1},             // decode attention at head_dim 128 / bf16: the lean kernel (attn_decode128_kernel); 0 = the generic kernel
     {"FP8_MASK", 6},                // e4m3 encoder mode: which projections take e4m3 operands (bit 0 qkv, 1 out, 2 fc1, 3 fc2)
     {"FP8_FC2", 0},                 // ... fc2 as well
     {"GEMM_SMALL_TILE", 0},

@@ -647,6 +647,234 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
     op[d] = from_f32<T>(y);
 }
 
+
+// ---- decode attention at head_dim 128, bf16: one new token per sequence against its KV cache (round 4) ----------------------------------
+// The generic kernel above keeps the GQA group's few query rows in one wave and walks its key range as two LDS-staged tiles, the second
+// requested only after the first has landed: a 10-us launch for 0.4 MB.  Here a workgroup takes the same (sequence, kv head, 128-key range)
+// and the same partial format (the merge pass is unchanged), but
+//   * every byte it needs -- K and V rows of its 128 keys, q, the cos / sin row -- is requested before anything is waited for;
+//   * K goes straight from global memory into the A operand of v_mfma_f32_16x16x32_bf16 (lane (key, 16-byte chunk) = one 16-byte load, no
+//     LDS staging, no barrier); each wave owns 32 keys: S[32 keys, 16 query slots] = 8 MFMAs;
+//   * P.V runs on the vector ALU (<= 8 query rows x 8 keys x 8 columns per lane: 512 fma) on V rows loaded in their natural layout -- the
+//     matrix pipe would want V transposed, which is what the LDS round trip of the generic kernel is for;
+//   * the four waves' partial softmaxes (and the four key quarters inside a wave) meet once, through LDS, in fixed order.
+// Fused RoPE + KV append as in attn_kernel (same rope_mad, same bits in the cache).  Masked key slots re-read the last live row and their V is
+// forced to zero, so nothing behind the context -- uninitialised cache, the row being appended -- can reach the output.
+constexpr int DL_REP = 8;                                   // query rows (GQA group size) this form holds
+constexpr int DL_LDS_P = 4 * 64 * 8 * 4;                    // P of each wave: [key quarter][query slot][8 keys] f32
+constexpr int DL_LDS_O = 16 * DL_REP * 128 * 4;             // partial O: [wave][key quarter][query][128] f32
+constexpr int DL_LDS = DL_LDS_P + DL_LDS_O + 4 * DL_REP * 2 * 4;
+#ifdef AFHIP_ATTN_STAMPS   /* diagnostic build (tools/decode_attn_stamps.py): 100-MHz wall clock of wave 0 of every workgroup */
+#define DL_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DL_STAMP(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    DL_STAMP(0);
+    const int nh = p.n_q * p.B;
+    int xt, hb;
+    if ((nh & 7) == 0) {                                    // same XCD-aware order as attn_kernel: the ranges of one (sequence, head) share an L2
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        xt = r % p.n_xt;
+        hb = (r / p.n_xt) * 8 + xcd;
+    } else {
+        xt = blockIdx.x % p.n_xt;
+        hb = blockIdx.x / p.n_xt;
+    }
+    const int b = hb / p.n_q, hkv = hb % p.n_q;
+    const int rep = p.Tq;
+    int klen = p.Tk;
+    if (p.seq_pos) { const int tk = p.seq_pos[b] + 1; klen = tk < klen ? tk : klen; }
+    const int tk_b = klen;
+    const int kbeg = xt * p.key_split;
+    const int kend = (kbeg + p.key_split) < klen ? (kbeg + p.key_split) : klen;
+    if (kbeg >= kend) return;                               // range beyond this sequence's context (the merge derives the live ranges the same way)
+    DL_STAMP(1);
+    const char* qb = p.q + ((long long)b * p.q_bs + (long long)hkv * p.q_hs) * 2;
+    const char* kb = p.k + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * 2;
+    const char* vb = p.v + ((long long)b * p.kv_bs + (long long)hkv * p.kv_hs) * 2;
+    const unsigned rowb = (unsigned)(p.ld_kv * 2);          // one (sequence, head)'s cache is far below 4 GiB (host check): 32-bit offsets inside it
+    const float* rope_cos = p.rope_cos;
+    const float* rope_sin = p.rope_sin;
+    if (p.seq_pos && p.new_k) { rope_cos += (long long)(tk_b - 1) * 64; rope_sin += (long long)(tk_b - 1) * 64; }
+    const int wk0 = kbeg + 32 * wave;                       // this wave's 32 keys
+    const bool fused = p.new_k != nullptr;
+    const char* nk = fused ? p.new_k + ((long long)b * p.new_kv_bs + (long long)hkv * 128) * 2 : nullptr;
+    const char* nv = fused ? p.new_v + ((long long)b * p.new_kv_bs + (long long)hkv * 128) * 2 : nullptr;
+
+    // ---- every load of the launch ----
+    u32x4 kf[2][4], vf[8], qf[4];
+    f32x4 cs[2][2], sn[2][2];                               // cos / sin of rotation pairs 32 s + 8 g .. + 8 (s = 0, 1)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int key = wk0 + 16 * blk + c;
+        const int kc = key < klen ? key : klen - 1;
+        const char* row = (fused && key == tk_b - 1) ? nk : kb + (unsigned)kc * rowb;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[blk][s] = ld16(row + (4 * s + g) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int key = wk0 + 16 * (k >> 2) + 4 * g + (k & 3);
+        const int kc = key < klen ? key : klen - 1;
+        const char* row = (fused && key == tk_b - 1) ? nv : vb + (unsigned)kc * rowb;
+        vf[k] = ld16(row + c * 16);
+    }
+    {
+        const int j = c < rep ? c : rep - 1;
+        const char* qrow = qb + (long long)j * p.ld_q * 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = ld16(qrow + (4 * s + g) * 16);
+    }
+    if (fused) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cs[s][h] = *reinterpret_cast<const f32x4*>(rope_cos + 32 * s + 8 * g + 4 * h);
+                sn[s][h] = *reinterpret_cast<const f32x4*>(rope_sin + 32 * s + 8 * g + 4 * h);
+            }
+        // rotate-half RoPE: element d = 32 s + 8 g + e (s = 0, 1) pairs with d + 64 = k-step s + 2 of the SAME lane.  q cos + rotate_half(q) sin
+        // with separate roundings, then bf16 -- exactly rope_kv_kernel (norm.hip) and attn_kernel
+        auto rotate = [&](u32x4 (&x)[4]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16 lo[8], hi[8];
+                *reinterpret_cast<u32x4*>(lo) = x[s];
+                *reinterpret_cast<u32x4*>(hi) = x[s + 2];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float cc = cs[s][e >> 2][e & 3], ss = sn[s][e >> 2][e & 3];
+                    const float x1 = (float)lo[e], x2 = (float)hi[e];
+                    lo[e] = (bf16)rope_mad(x1, cc, -x2, ss);
+                    hi[e] = (bf16)rope_mad(x2, cc, x1, ss);
+                }
+                x[s] = *reinterpret_cast<const u32x4*>(lo);
+                x[s + 2] = *reinterpret_cast<const u32x4*>(hi);
+            }
+        };
+        rotate(qf);
+        // the token being generated: its k is rotated here, and k, v are written to the cache for the following steps (only the lanes of the
+        // one workgroup whose range holds position tk_b - 1 get here)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int key = wk0 + 16 * blk + c;
+            if (key == tk_b - 1) {
+                rotate(kf[blk]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) st16(const_cast<char*>(kb) + (unsigned)key * rowb + (4 * s + g) * 16, kf[blk][s]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int key = wk0 + 16 * (k >> 2) + 4 * g + (k & 3);
+            if (key == tk_b - 1) st16(const_cast<char*>(vb) + (unsigned)key * rowb + c * 16, vf[k]);
+        }
+    }
+
+    DL_STAMP(2);
+    // ---- S[key, query slot] for this wave's 32 keys ----
+    f32x4 sacc[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        sacc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            sacc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[blk][s]), __builtin_bit_cast(bf16x8, qf[s]), sacc[blk], 0, 0, 0);
+    }
+    // lane (g, c) holds, for query slot c, the scores of keys wk0 + 16 blk + 4 g + r: the same 8 keys whose V rows lane group g loaded
+    float sv[8], pv[8];
+#ifdef AFHIP_ATTN_STAMPS
+    { float t_ = sacc[0][0] + sacc[1][0]; asm volatile("" :: "v"(t_)); }
+    DL_STAMP(3);
+#endif
+    bool ok[8];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int key = wk0 + 16 * (k >> 2) + 4 * g + (k & 3);
+        ok[k] = key < kend;
+        sv[k] = sacc[k >> 2][k & 3];
+        mloc = ok[k] ? fmaxf(mloc, sv[k]) : mloc;
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_use = (mloc == -INFINITY) ? 0.f : mloc;
+    const float moff = -m_use * p.scale_log2;
+    float lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pv[k] = ok[k] ? __builtin_amdgcn_exp2f(fmaf(sv[k], p.scale_log2, moff)) : 0.f;
+        lsum += pv[k];
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    float* Pw = reinterpret_cast<float*>(smem) + wave * 512;
+    *reinterpret_cast<f32x4*>(Pw + (g * 16 + c) * 8) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+    *reinterpret_cast<f32x4*>(Pw + (g * 16 + c) * 8 + 4) = f32x4{pv[4], pv[5], pv[6], pv[7]};
+
+    // ---- O[query, 8 c .. 8 c + 8] over this lane's 8 keys ----
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t vv[8][4];                                       // column pairs: the fma below is v_pk_fma_f32
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t w = ok[k] ? vf[k][e] : 0u;       // two bf16: widening is a shift / a mask
+            vv[k][e] = f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+        }
+    DL_STAMP(4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's P tile is in LDS (one wave: no barrier)
+    __builtin_amdgcn_wave_barrier();
+    float* Op = reinterpret_cast<float*>(smem + DL_LDS_P);
+    float* ML = reinterpret_cast<float*>(smem + DL_LDS_P + DL_LDS_O);
+#pragma unroll
+    for (int q = 0; q < DL_REP; ++q) {
+        if (q < rep) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(Pw + (g * 16 + q) * 8), p1 = *reinterpret_cast<const f32x4*>(Pw + (g * 16 + q) * 8 + 4);
+            const float pq[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            f32x2_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32x2_t{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __builtin_elementwise_fma(f32x2_t{pq[k], pq[k]}, vv[k][e], o[e]);
+            float* dst = Op + (((wave * 4 + g) * DL_REP + q) * 128 + 8 * c);
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[2][0], o[2][1], o[3][0], o[3][1]};
+        }
+    }
+    if (g == 0 && c < DL_REP) { ML[(wave * DL_REP + c) * 2] = mloc; ML[(wave * DL_REP + c) * 2 + 1] = lsum; }
+    DL_STAMP(5);
+    __syncthreads();
+    DL_STAMP(6);
+
+    // ---- the four waves meet: same weights, same order for every output column ----
+    for (int idx = tid; idx < rep * 128; idx += 256) {
+        const int q = idx >> 7, d = idx & 127;
+        float mw[4], mt = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { mw[w] = ML[(w * DL_REP + q) * 2]; mt = fmaxf(mt, mw[w]); }
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float al = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mw[w] - mt) * p.scale_log2);
+            const float* src = Op + ((w * 4) * DL_REP + q) * 128 + d;
+            const float sw = ((src[0] + src[DL_REP * 128]) + src[2 * DL_REP * 128]) + src[3 * DL_REP * 128];
+            acc = fmaf(sw, al, acc);
+            l = fmaf(ML[(w * DL_REP + q) * 2 + 1], al, l);
+        }
+        const long long slot = (((long long)xt * p.B + b) * p.n_q + hkv) * 32 + q;
+        p.part_o[slot * 128 + d] = acc;
+        if (d == 0) { p.part_ml[slot * 2] = mt; p.part_ml[slot * 2 + 1] = l; }
+    }
+    DL_STAMP(7);
+}
+
 }  // namespace
 
 bool afhip_attention_enc64(const afhip_attn_args* a, hipStream_t s);   // attention_enc.hip: the one-wave-per-SIMD encoder form
@@ -739,6 +967,16 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
             (void)hipFuncSetAttribute((const void*)attn_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 128 * 4);
         }
     }
+    // decode at head_dim 128, bf16, a GQA group of at most 8 query rows, ranges of at most 128 keys: the lean form (same partials, same merge)
+    const bool lean = a->dtype == AFHIP_BF16 && a->hd == 128 && a->key_split > 0 && a->key_split <= 128 && a->Tq <= DL_REP && !a->causal &&
+                      a->key_len == nullptr && a->row_off == nullptr && a->split_ticket == nullptr && a->n_q == a->n_kv &&
+                      afhip_opt(AFHIP_OPT_DECODE_LEAN) != 0;
+    if (lean) {
+        static unsigned long long lean_attr = 0;
+        if (afhip_first_use_on_device(&lean_attr))
+            (void)hipFuncSetAttribute((const void*)attn_decode128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS);
+        hipLaunchKernelGGL(attn_decode128_kernel, grid, block, DL_LDS, s, p);
+    } else {
 #define AFHIP_ATTN_LAUNCH(TT, HH)                                                                          \
     do {                                                                                                   \
         if (nbuf == 2) hipLaunchKernelGGL((attn_kernel<TT, HH, 2>), grid, block, lds, s, p);             \
@@ -751,6 +989,7 @@ extern "C" int afhip_attention(const afhip_attn_args* a, void* stream) {
         if (a->hd == 64) AFHIP_ATTN_LAUNCH(bf16, 64); else AFHIP_ATTN_LAUNCH(bf16, 128);
     } else {
         if (a->hd == 64) AFHIP_ATTN_LAUNCH(float, 64); else AFHIP_ATTN_LAUNCH(float, 128);
+    }
     }
 #undef AFHIP_ATTN_LAUNCH
     AFHIP_LAUNCH_CHECK();

@@ -52,7 +52,7 @@ int afhip_cu_count();
 // paths read an int from the table: no getenv, no string compare.
 enum afhip_opt_id {
     AFHIP_OPT_ATTN_NBUF, AFHIP_OPT_ATTN_LDS_PAD, AFHIP_OPT_ATTN_LAG, AFHIP_OPT_ATTN_ENC64, AFHIP_OPT_ENC64_ONE_BLOCK_PER_WG,
-    AFHIP_OPT_DECODE_IMAGED, AFHIP_OPT_DECODE_MERGE, AFHIP_OPT_DECODE_KEY_SPLIT, AFHIP_OPT_FP8_MASK, AFHIP_OPT_FP8_FC2,
+    AFHIP_OPT_DECODE_IMAGED, AFHIP_OPT_DECODE_MERGE, AFHIP_OPT_DECODE_KEY_SPLIT, AFHIP_OPT_DECODE_LEAN, AFHIP_OPT_FP8_MASK, AFHIP_OPT_FP8_FC2,
     AFHIP_OPT_GEMM_SMALL_TILE, AFHIP_OPT_GEMM_GROUP_M, AFHIP_OPT_GEMM_MFMA16, AFHIP_OPT_GEMM_PP,
     AFHIP_OPT_SKINNY_ALDS, AFHIP_OPT_SKINNY_STREAM, AFHIP_OPT_SKINNY_PERSIST, AFHIP_OPT_LOGMEL_DFT, AFHIP_OPT_COUNT
 };

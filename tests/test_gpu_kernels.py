@@ -599,15 +599,76 @@ def test_attention_decode_fused_rope_append_is_bit_identical(dt, nq, nkv, hd, tk
     assert torch.equal(out_a, out_b)
     assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
     assert torch.equal(q_b, qkv.reshape(B, qw))          # the fused form leaves the projection output untouched
-    # ... and with the partial softmaxes merged inside the launch (last-arriver ticket) instead of by a second pass
-    kc_c, vc_c = kc0.clone(), vc0.clone()
-    for rep_ in range(3):                                  # repeated launches: the ticket must come back to zero
-        out_c = ops.attention_decode(q_b, kc_c, vc_c, nq, nkv, tk, key_split=128, ld_q=qw, fused_rope=(q_b, cos[pos].contiguous(), sin[pos].contiguous()),
-                                     in_launch_merge=True)
-        assert torch.equal(out_a, out_c), f"in-launch merge differs (launch {rep_})"
-    out_d = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw, in_launch_merge=True)
-    out_e = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw)
-    assert torch.equal(out_d, out_e)
+    # ... and with the partial softmaxes merged inside the launch (last-arriver ticket) instead of by a second pass.  The ticket form lives in
+    # the generic kernel only, so its partner is the generic kernel's two-pass form (option DECODE_LEAN = 0; at head_dim 128 / bf16 the
+    # default two-pass form is the lean decode kernel, whose bits differ)
+    _opt("DECODE_LEAN", 0)
+    try:
+        out_g = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=128, ld_q=qw)
+        kc_c, vc_c = kc0.clone(), vc0.clone()
+        for rep_ in range(3):                                  # repeated launches: the ticket must come back to zero
+            out_c = ops.attention_decode(q_b, kc_c, vc_c, nq, nkv, tk, key_split=128, ld_q=qw, fused_rope=(q_b, cos[pos].contiguous(), sin[pos].contiguous()),
+                                         in_launch_merge=True)
+            assert torch.equal(out_g, out_c), f"in-launch merge differs (launch {rep_})"
+        assert torch.equal(kc_c, kc_a) and torch.equal(vc_c, vc_a)
+        out_d = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw, in_launch_merge=True)
+        out_e = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw)
+        assert torch.equal(out_d, out_e)
+    finally:
+        _opt("DECODE_LEAN", 1)
+    # the lean and the generic kernel: different summation orders of the same softmax
+    lim = 1e-5 if dt == torch.float32 else 2e-2
+    assert float((out_g.float() - out_a.float()).abs().max()) <= lim * (1.0 + float(out_g.float().abs().max()))
+
+
+@pytest.mark.parametrize("rep,nkv", [(7, 4), (8, 2), (4, 4), (1, 8)])
+@pytest.mark.parametrize("tk", [1, 31, 127, 128, 129, 517, 890, 2305])
+def test_attention_decode_lean_kernel(rep, nkv, tk):
+    """attn_decode128_kernel (bf16, head_dim 128, a GQA group of at most 8 rows): every load up front, K straight into the MFMA, P.V on the vector
+    ALU, one LDS meeting of the four waves.  Against the fp32 softmax at context lengths around every boundary it has (one key, a quarter
+    wave, one range, one key into the next range, many ranges -- 2305 takes the merge's general path), with NaNs behind the context in the
+    cache, and fused RoPE + append against the two-launch form bit for bit."""
+    from audio_intelligence_amd import ops
+    import ctypes as C
+    from audio_intelligence_amd import _lib as L
+    dt, hd, B = torch.bfloat16, 128, 3
+    nq = rep * nkv
+    cap = 2432
+    qw = (nq + 2 * nkv) * hd
+    qkv, qkvf = _q(_rand(B, 1, qw, seed=171 + tk), dt)
+    kc0, kf = _q(_rand(B, nkv, cap, hd, seed=172), dt)
+    vc0, vf = _q(_rand(B, nkv, cap, hd, seed=173), dt)
+    kc0[:, :, tk:] = float("nan")                          # whatever sits behind the context must not reach the output
+    vc0[:, :, tk:] = float("nan")
+    inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.arange(cap).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous().to(_dev()), ang.sin().contiguous().to(_dev())
+    pos = tk - 1
+    # two launches: rope + append, then attention
+    q_a, kc_a, vc_a = qkv.clone(), kc0.clone(), vc0.clone()
+    ops.rope_kv(q_a, cos, sin, pos, kc_a, vc_a, nq, nkv)
+    out_a = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=128, ld_q=qw)
+    assert bool(torch.isfinite(out_a.float()).all())
+    ref = _ref_attention(q_a.reshape(B, qw)[:, : nq * hd].float().cpu().reshape(B, 1, nq, hd),
+                         kc_a[:, :, :tk].float().cpu().permute(0, 2, 1, 3), vc_a[:, :, :tk].float().cpu().permute(0, 2, 1, 3))
+    _check(out_a, ref.reshape(B, nq * hd), 2e-2, 2e-2, f"lean decode attention rep={rep} tk={tk}")
+    # fused: same bits in the output and in the cache rows written; the projection output untouched
+    q_b, kc_b, vc_b = qkv.clone().reshape(B, qw), kc0.clone(), vc0.clone()
+    out_b = ops.attention_decode(q_b, kc_b, vc_b, nq, nkv, tk, key_split=128, ld_q=qw, fused_rope=(q_b, cos[pos].contiguous(), sin[pos].contiguous()))
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(kc_a[:, :, :tk], kc_b[:, :, :tk]) and torch.equal(vc_a[:, :, :tk], vc_b[:, :, :tk])
+    assert bool(torch.isnan(kc_b[:, :, tk:].float()).all()) and bool(torch.isnan(vc_b[:, :, tk:].float()).all())     # nothing written behind the context
+    assert torch.equal(q_b, qkv.reshape(B, qw))
+    # the generic kernel on the same inputs: the same softmax in another order
+    _opt("DECODE_LEAN", 0)
+    try:
+        out_g = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=128, ld_q=qw)
+    finally:
+        _opt("DECODE_LEAN", 1)
+    assert float((out_g.float() - out_a.float()).abs().max()) <= 2e-2 * (1.0 + float(out_g.float().abs().max()))
+    # narrower ranges (64 keys: two waves of a workgroup idle) give the same answer to rounding
+    out_n = ops.attention_decode(q_a.reshape(B, qw), kc_a, vc_a, nq, nkv, tk, key_split=64, ld_q=qw)
+    _check(out_n, ref.reshape(B, nq * hd), 2e-2, 2e-2, f"lean decode attention rep={rep} tk={tk} split 64")
 
 
 def test_torch_library_ops_dispatch_to_the_hip_library():
