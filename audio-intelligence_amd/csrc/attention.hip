@@ -660,16 +660,27 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 //   * the four waves' partial softmaxes (and the four key quarters inside a wave) meet once, through LDS, in fixed order.
 // Fused RoPE + KV append as in attn_kernel (same rope_mad, same bits in the cache).  Masked key slots re-read the last live row and their V is
 // forced to zero, so nothing behind the context -- uninitialised cache, the row being appended -- can reach the output.
+// the kernel arguments go through an opaque scalar copy (below); these put the global address space back on what is loaded through them
+#define DL_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 ldg16(const void* q) { return *(const DL_AS1 u32x4*)q; }
+__device__ __forceinline__ void stg16(void* q, u32x4 v) { *(DL_AS1 u32x4*)q = v; }
 constexpr int DL_REP = 8;                                   // query rows (GQA group size) this form holds
 constexpr int DL_LDS_P = 4 * 64 * 8 * 4;                    // P of each wave: [key quarter][query slot][8 keys] f32
 constexpr int DL_LDS_O = 16 * DL_REP * 128 * 4;             // partial O: [wave][key quarter][query][128] f32
 constexpr int DL_LDS = DL_LDS_P + DL_LDS_O + 4 * DL_REP * 2 * 4;
 #ifdef AFHIP_ATTN_STAMPS   /* diagnostic build (tools/decode_attn_stamps.py): 100-MHz wall clock of wave 0 of every workgroup */
-#define DL_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DL_STAMP(k) do { if (p.dbg && tid == 0) ((DL_AS1 unsigned long long*)p.dbg)[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define DL_STAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
+__global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p_in) {
+    // every kernel argument this launch reads, fetched in ONE batch: left to itself the compiler loads the fields where they are first needed,
+    // five dependent scalar round trips (0.3-0.5 us each) before the first K row is requested
+    AttnP p = p_in;
+    asm volatile("" : "+s"(p.q), "+s"(p.k), "+s"(p.v), "+s"(p.B), "+s"(p.Tq), "+s"(p.Tk), "+s"(p.n_q), "+s"(p.ld_q), "+s"(p.ld_kv),
+                 "+s"(p.q_bs), "+s"(p.kv_bs), "+s"(p.q_hs), "+s"(p.kv_hs), "+s"(p.scale_log2), "+s"(p.n_xt), "+s"(p.key_split));
+    asm volatile("" : "+s"(p.part_o), "+s"(p.part_ml), "+s"(p.new_k), "+s"(p.new_v), "+s"(p.new_kv_bs), "+s"(p.rope_cos), "+s"(p.rope_sin),
+                 "+s"(p.seq_pos), "+s"(p.dbg));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
     const int b = hb / p.n_q, hkv = hb % p.n_q;
     const int rep = p.Tq;
     int klen = p.Tk;
-    if (p.seq_pos) { const int tk = p.seq_pos[b] + 1; klen = tk < klen ? tk : klen; }
+    if (p.seq_pos) { const int tk = ((const DL_AS1 int32_t*)p.seq_pos)[b] + 1; klen = tk < klen ? tk : klen; }
     const int tk_b = klen;
     const int kbeg = xt * p.key_split;
     const int kend = (kbeg + p.key_split) < klen ? (kbeg + p.key_split) : klen;
@@ -714,28 +725,28 @@ __global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
         const int kc = key < klen ? key : klen - 1;
         const char* row = (fused && key == tk_b - 1) ? nk : kb + (unsigned)kc * rowb;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[blk][s] = ld16(row + (4 * s + g) * 16);
+        for (int s = 0; s < 4; ++s) kf[blk][s] = ldg16(row + (4 * s + g) * 16);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int key = wk0 + 16 * (k >> 2) + 4 * g + (k & 3);
         const int kc = key < klen ? key : klen - 1;
         const char* row = (fused && key == tk_b - 1) ? nv : vb + (unsigned)kc * rowb;
-        vf[k] = ld16(row + c * 16);
+        vf[k] = ldg16(row + c * 16);
     }
     {
         const int j = c < rep ? c : rep - 1;
         const char* qrow = qb + (long long)j * p.ld_q * 2;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = ld16(qrow + (4 * s + g) * 16);
+        for (int s = 0; s < 4; ++s) qf[s] = ldg16(qrow + (4 * s + g) * 16);
     }
     if (fused) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                cs[s][h] = *reinterpret_cast<const f32x4*>(rope_cos + 32 * s + 8 * g + 4 * h);
-                sn[s][h] = *reinterpret_cast<const f32x4*>(rope_sin + 32 * s + 8 * g + 4 * h);
+                cs[s][h] = *(const DL_AS1 f32x4*)(rope_cos + 32 * s + 8 * g + 4 * h);
+                sn[s][h] = *(const DL_AS1 f32x4*)(rope_sin + 32 * s + 8 * g + 4 * h);
             }
         // rotate-half RoPE: element d = 32 s + 8 g + e (s = 0, 1) pairs with d + 64 = k-step s + 2 of the SAME lane.  q cos + rotate_half(q) sin
         // with separate roundings, then bf16 -- exactly rope_kv_kernel (norm.hip) and attn_kernel
@@ -765,13 +776,13 @@ __global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
             if (key == tk_b - 1) {
                 rotate(kf[blk]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) st16(const_cast<char*>(kb) + (unsigned)key * rowb + (4 * s + g) * 16, kf[blk][s]);
+                for (int s = 0; s < 4; ++s) stg16(const_cast<char*>(kb) + (unsigned)key * rowb + (4 * s + g) * 16, kf[blk][s]);
             }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int key = wk0 + 16 * (k >> 2) + 4 * g + (k & 3);
-            if (key == tk_b - 1) st16(const_cast<char*>(vb) + (unsigned)key * rowb + c * 16, vf[k]);
+            if (key == tk_b - 1) stg16(const_cast<char*>(vb) + (unsigned)key * rowb + c * 16, vf[k]);
         }
     }
 
@@ -869,8 +880,8 @@ __global__ __launch_bounds__(256) void attn_decode128_kernel(AttnP p) {
             l = fmaf(ML[(w * DL_REP + q) * 2 + 1], al, l);
         }
         const long long slot = (((long long)xt * p.B + b) * p.n_q + hkv) * 32 + q;
-        p.part_o[slot * 128 + d] = acc;
-        if (d == 0) { p.part_ml[slot * 2] = mt; p.part_ml[slot * 2 + 1] = l; }
+        ((DL_AS1 float*)p.part_o)[slot * 128 + d] = acc;
+        if (d == 0) { ((DL_AS1 float*)p.part_ml)[slot * 2] = mt; ((DL_AS1 float*)p.part_ml)[slot * 2 + 1] = l; }
     }
     DL_STAMP(7);
 }

@@ -18,10 +18,16 @@
 
 namespace stream {
 
-__device__ __forceinline__ u32x4 ld16g(const char* base, long long off) { return *reinterpret_cast<const u32x4*>(base + off); }
-__device__ __forceinline__ float ld_bf16g(const char* base, long long off) { return (float)*reinterpret_cast<const bf16*>(base + off); }
-__device__ __forceinline__ void st_bf16g(char* base, long long off, float v) { *reinterpret_cast<bf16*>(base + off) = (bf16)v; }
-__device__ __forceinline__ void st_f32g(char* base, long long off, float v) { *reinterpret_cast<float*>(base + off) = v; }
+// Every pointer of a phase descriptor has been through an opaque scalar copy (opq below), after which the compiler no longer knows that it
+// points to global memory and would emit FLAT loads: those count on lgkmcnt as well, so every LDS wait of the per-unit combine would drain
+// the weight window in flight.  These helpers put the address space back.
+#define STREAM_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 ld16g(const void* base, long long off) { return *(const STREAM_AS1 u32x4*)((const char*)base + off); }
+__device__ __forceinline__ float ld_bf16g(const void* base, long long off) { return (float)*(const STREAM_AS1 bf16*)((const char*)base + off); }
+__device__ __forceinline__ float ld_f32g(const void* base, long long off) { return *(const STREAM_AS1 float*)((const char*)base + off); }
+__device__ __forceinline__ int ld_i32g(const void* base, long long off) { return *(const STREAM_AS1 int*)((const char*)base + off); }
+__device__ __forceinline__ void st_bf16g(void* base, long long off, float v) { *(STREAM_AS1 bf16*)((char*)base + off) = (bf16)v; }
+__device__ __forceinline__ void st_f32g(void* base, long long off, float v) { *(STREAM_AS1 float*)((char*)base + off) = v; }
 
 // byte offset of element (row m, column k) in a fragment-order image of RM rows
 __device__ __forceinline__ long long img_off(int RM, int m, int k) {
@@ -125,7 +131,7 @@ struct ImgPhase {
         const int s = wave + NW * ij;
         const long long koff = (long long)s * 128 + q * 32;          // 32 bytes per lane and step in either weight format
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
+        for (int t = 0; t < NT; ++t) { x.w0[t] = ld16g(wrow[t], koff); x.w1[t] = ld16g(wrow[t], koff + 16); }
         issue_a(x, s);
         ++ig;
         if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
@@ -142,10 +148,10 @@ struct ImgPhase {
                 const int n = (u * NT + nt) * TR + (ln & 15), m = 4 * (ln >> 4) + reg;
                 const bool ok = o < NT * 256 && (ln & 15) < TR && n < p.N && m < p.M;
                 const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional
-                ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
-                ep_g[i] = p.img_gain ? (float)reinterpret_cast<const bf16*>(p.img_gain)[nc] : 1.f;
+                ep_b[i] = p.bias ? ld_bf16g(p.bias, (long long)nc * 2) : 0.f;
+                ep_g[i] = p.img_gain ? ld_bf16g(p.img_gain, (long long)nc * 2) : 1.f;
                 ep_r[i] = p.res ? ld_bf16g(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
-                ep_s[i] = W8 ? p.w_scale[nc] : 1.f;
+                ep_s[i] = W8 ? ld_f32g(p.w_scale, (long long)nc * 4) : 1.f;
             }
         }
     }
@@ -158,7 +164,7 @@ struct ImgPhase {
             for (int k = 0; k < 4; ++k) {
                 const int j = lane + 64 * k;
                 const int jc = j < p.ss_n ? j : p.ss_n - 1;                 // clamped: unconditional loads
-                const float v = p.ss_in[m * p.ss_n + jc];
+                const float v = ld_f32g(p.ss_in, (long long)(m * p.ss_n + jc) * 4);
                 ssv[ri][k] = j < p.ss_n ? v : 0.f;
             }
         }
@@ -227,7 +233,7 @@ struct ImgPhase {
                     }
                     if constexpr (W8) {
                         const int ng = ((gi >> 5) << 6) + (gi & 31);
-                        g *= p.w_scale[ng]; uu *= p.w_scale[ng + 32];
+                        g *= ld_f32g(p.w_scale, (long long)ng * 4); uu *= ld_f32g(p.w_scale, (long long)(ng + 32) * 4);
                     }
                     const float y = silu(g) * uu;
                     if (p.img_out) st_bf16g(p.img_out, img_off(RM, mrow, gi), y);
@@ -261,7 +267,7 @@ struct ImgPhase {
                         }
                         if (p.am_val) {
                             bool ok = false;
-                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= p.am_iv[2 * k] && nn < p.am_iv[2 * k + 1]);
+                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
                             const float vb = (float)(bf16)v;           // the reference takes argmax over model-dtype logits
                             if (ok && (vb > am_best || (vb == am_best && nn < am_bi))) { am_best = vb; am_bi = nn; }
                         }
@@ -279,7 +285,7 @@ struct ImgPhase {
             for (int ri = 0; ri < RM / 8; ++ri) {
                 float t = ((ssv[ri][0] + ssv[ri][1]) + ssv[ri][2]) + ssv[ri][3];
                 const int m = wave + 8 * ri;
-                for (int j = lane + 256; j < p.ss_n; j += 64) t += p.ss_in[m * p.ss_n + j];      // more than 256 producing workgroups: the rest, the slow way
+                for (int j = lane + 256; j < p.ss_n; j += 64) t += ld_f32g(p.ss_in, (long long)(m * p.ss_n + j) * 4);      // more than 256 producing workgroups: the rest, the slow way
                 ssp[ri] = t;
             }
         }
