@@ -24,6 +24,8 @@ namespace stream {
 #define STREAM_AS1 __attribute__((address_space(1)))
 __device__ __forceinline__ u32x4 ld16g(const void* base, long long off) { return *(const STREAM_AS1 u32x4*)((const char*)base + off); }
 __device__ __forceinline__ float ld_bf16g(const void* base, long long off) { return (float)*(const STREAM_AS1 bf16*)((const char*)base + off); }
+__device__ __forceinline__ unsigned short ld_u16g(const void* base, long long off) { return *(const STREAM_AS1 unsigned short*)((const char*)base + off); }
+__device__ __forceinline__ float bf16_bits_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ float ld_f32g(const void* base, long long off) { return *(const STREAM_AS1 float*)((const char*)base + off); }
 __device__ __forceinline__ int ld_i32g(const void* base, long long off) { return *(const STREAM_AS1 int*)((const char*)base + off); }
 __device__ __forceinline__ void st_bf16g(void* base, long long off, float v) { *(STREAM_AS1 bf16*)((char*)base + off) = (bf16)v; }
@@ -68,7 +70,10 @@ struct ImgPhase {
     Regs r[DEPTH];
     long long aofs;
     int ig, iu, ij;
-    float ep_b[NI], ep_r[NI], ep_g[NI], ep_s[NI];
+    // epilogue operands as LOADED (bf16 bits): widening them where they are fetched made the wave wait for them -- and, vmcnt being in order, for
+    // the whole weight window issued just before -- at the top of the kernel instead of at the unit's end
+    unsigned short ep_b[NI], ep_r[NI], ep_g[NI];
+    float ep_s[NI];
     float ssp[2];      // this lane's share of the partial sums of squares of rows wave, wave + 8
     float ssv[RM / 8][4];  // ... as loaded (up to 256 partials per row: four per lane), summed when the K loop is about to start
     f32x4 acc[NT];
@@ -148,9 +153,9 @@ struct ImgPhase {
                 const int n = (u * NT + nt) * TR + (ln & 15), m = 4 * (ln >> 4) + reg;
                 const bool ok = o < NT * 256 && (ln & 15) < TR && n < p.N && m < p.M;
                 const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional
-                ep_b[i] = p.bias ? ld_bf16g(p.bias, (long long)nc * 2) : 0.f;
-                ep_g[i] = p.img_gain ? ld_bf16g(p.img_gain, (long long)nc * 2) : 1.f;
-                ep_r[i] = p.res ? ld_bf16g(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
+                ep_b[i] = p.bias ? ld_u16g(p.bias, (long long)nc * 2) : (unsigned short)0;
+                ep_g[i] = p.img_gain ? ld_u16g(p.img_gain, (long long)nc * 2) : (unsigned short)0x3f80;      // 1.0
+                ep_r[i] = p.res ? ld_u16g(p.res, ((long long)mc * p.ldres + nc) * 2) : (unsigned short)0;
                 ep_s[i] = W8 ? ld_f32g(p.w_scale, (long long)nc * 4) : 1.f;
             }
         }
@@ -253,8 +258,8 @@ struct ImgPhase {
                     if ((ln & 15) < TR && nn < p.N && mm < p.M) {
                         if constexpr (RMS) v *= rsqrtf(red_ss[mm] / (float)p.K + p.eps);
                         if constexpr (W8) v *= ep_s[i];
-                        if (p.bias) v += ep_b[i];
-                        if (p.res) v += ep_r[i];
+                        if (p.bias) v += bf16_bits_f32(ep_b[i]);
+                        if (p.res) v += bf16_bits_f32(ep_r[i]);
                         if (p.C) {
                             if (p.out_f32) st_f32g(p.C, ((long long)mm * p.ldc + nn) * 4, v);
                             else st_bf16g(p.C, ((long long)mm * p.ldc + nn) * 2, v);
@@ -262,7 +267,7 @@ struct ImgPhase {
                         if (p.img_out) {
                             // the stored (bf16) value is what the next RMSNorm sees: gain applied to it, its square summed
                             const float xb = (float)(bf16)v;
-                            st_bf16g(p.img_out, img_off(RM, mm, nn), xb * ep_g[i]);
+                            st_bf16g(p.img_out, img_off(RM, mm, nn), xb * bf16_bits_f32(ep_g[i]));
                             ss_acc += xb * xb;
                         }
                         if (p.am_val) {
