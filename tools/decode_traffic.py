@@ -12,7 +12,7 @@ import re
 import sys
 
 # the kernels of the decode step; rmsnorm / gemm_pp / rope launches in the same trace belong to the prefill
-STEP_KERNELS = ("img_phase_kernel", "attn_kernel", "attn_combine_kernel", "embed_kernel", "pick_kernel")
+STEP_KERNELS = ("img_phase_kernel", "attn_kernel", "attn_decode128_kernel", "attn_combine_kernel", "embed_kernel", "pick_kernel")
 
 
 def short(name):
@@ -50,7 +50,7 @@ def main():
         n = max(n, n2)
         per_launch = 2.0 * 1024.0 * rd + 1024.0 * wr
         cnt = round(n / steps)
-        if cnt == 0:
+        if cnt == 0 or n % steps != 0:            # not once (or k times) per step: a prefill launch of a kernel the step shares a name with
             continue
         kernels[k] = {"hbm_read_bytes_per_launch": 2048.0 * rd, "hbm_write_bytes_per_launch": 1024.0 * wr, "launches_per_step": cnt, "launches_sampled": n}
         per_step += per_launch * cnt
