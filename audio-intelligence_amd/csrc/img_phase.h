@@ -18,19 +18,6 @@
 
 namespace stream {
 
-// Every pointer of a phase descriptor has been through an opaque scalar copy (opq below), after which the compiler no longer knows that it
-// points to global memory and would emit FLAT loads: those count on lgkmcnt as well, so every LDS wait of the per-unit combine would drain
-// the weight window in flight.  These helpers put the address space back.
-#define STREAM_AS1 __attribute__((address_space(1)))
-__device__ __forceinline__ u32x4 ld16g(const void* base, long long off) { return *(const STREAM_AS1 u32x4*)((const char*)base + off); }
-__device__ __forceinline__ float ld_bf16g(const void* base, long long off) { return (float)*(const STREAM_AS1 bf16*)((const char*)base + off); }
-__device__ __forceinline__ unsigned short ld_u16g(const void* base, long long off) { return *(const STREAM_AS1 unsigned short*)((const char*)base + off); }
-__device__ __forceinline__ float bf16_bits_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ float ld_f32g(const void* base, long long off) { return *(const STREAM_AS1 float*)((const char*)base + off); }
-__device__ __forceinline__ int ld_i32g(const void* base, long long off) { return *(const STREAM_AS1 int*)((const char*)base + off); }
-__device__ __forceinline__ void st_bf16g(void* base, long long off, float v) { *(STREAM_AS1 bf16*)((char*)base + off) = (bf16)v; }
-__device__ __forceinline__ void st_f32g(void* base, long long off, float v) { *(STREAM_AS1 float*)((char*)base + off) = v; }
-
 // byte offset of element (row m, column k) in a fragment-order image of RM rows
 __device__ __forceinline__ long long img_off(int RM, int m, int k) {
     return (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + m) << 4) + ((k & 7) << 1);

@@ -478,12 +478,18 @@ void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wa
 #endif
     float lr_t = lr, li_t = li;                                 // likewise the 25 per-lane W400 products of the unpack
     asm volatile("" : "+v"(lr_t), "+v"(li_t));
+    // an opaque move also hides the ADDRESS SPACE: through wn_t / tw_t the 50 table reads of a frame were FLAT loads that the memory pipeline
+    // routed to the LDS (vmcnt + lgkmcnt, TA issue) instead of ds_read_b64 -- the casts say "LDS" again
+    typedef const __attribute__((address_space(3))) f32x2 lds_f32x2_t;
+    typedef const __attribute__((address_space(3))) float lds_f32_t;
+    lds_f32_t* const wn_l = (lds_f32_t*)wn_t;
+    lds_f32_t* const tw_l = (lds_f32_t*)tw_t;
     // ---- load + window: z[m] = (x[16m + 2t], x[16m + 2t + 1]) . w ----
     float zr[25], zi[25];
 #pragma unroll
     for (int m = 0; m < 25; ++m) {
         const f32x2 xv = *reinterpret_cast<const f32x2*>(xs + (f + m / 10) * FFT_PITCH + 16 * (m % 10) + 2 * t);
-        const f32x2 wv = *reinterpret_cast<const f32x2*>(wn_t + 16 * m + 2 * t);
+        const f32x2 wv = *(lds_f32x2_t*)(wn_l + 16 * m + 2 * t);
         zr[m] = xv[0] * wv[0];
         zi[m] = xv[1] * wv[1];
     }
@@ -513,7 +519,7 @@ void logmel_pass1_fft(const float* __restrict__ wav, int n_samples, long long wa
 #pragma unroll
         for (int kb = 0; kb < 5; ++kb) {
             const int q = ka + 5 * kb;
-            const f32x2 tv = *reinterpret_cast<const f32x2*>(tw_t + 2 * (q * 8 + t));
+            const f32x2 tv = *(lds_f32x2_t*)(tw_l + 2 * (q * 8 + t));
             const float ar = zr[5 * ka + kb], ai = zi[5 * ka + kb];
             yr[q] = ar * tv[0] - ai * tv[1];
             yi[q] = ar * tv[1] + ai * tv[0];

@@ -22,6 +22,20 @@ namespace stream {
 
 constexpr int NW = 8, KS = 64;
 
+// Every pointer of a phase descriptor has been through an opaque scalar copy (opq in the phase structs), after which the compiler no longer knows that it
+// points to global memory and would emit FLAT loads: those count on lgkmcnt as well, so every LDS wait of the per-unit combine would drain
+// the weight window in flight.  These helpers put the address space back.
+#define STREAM_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 ld16g(const void* base, long long off) { return *(const STREAM_AS1 u32x4*)((const char*)base + off); }
+__device__ __forceinline__ float ld_bf16g(const void* base, long long off) { return (float)*(const STREAM_AS1 bf16*)((const char*)base + off); }
+__device__ __forceinline__ unsigned short ld_u16g(const void* base, long long off) { return *(const STREAM_AS1 unsigned short*)((const char*)base + off); }
+__device__ __forceinline__ float bf16_bits_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ float ld_f32g(const void* base, long long off) { return *(const STREAM_AS1 float*)((const char*)base + off); }
+__device__ __forceinline__ int ld_i32g(const void* base, long long off) { return *(const STREAM_AS1 int*)((const char*)base + off); }
+__device__ __forceinline__ void st_bf16g(void* base, long long off, float v) { *(STREAM_AS1 bf16*)((char*)base + off) = (bf16)v; }
+__device__ __forceinline__ void st_f32g(void* base, long long off, float v) { *(STREAM_AS1 float*)((char*)base + off) = v; }
+
+
 #ifdef AFHIP_STREAM_STAMPS   /* diagnostic build (tools/stream_stamps.py): 100-MHz wall-clock stamps of wave 0 of every workgroup */
 #define ST_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -126,14 +140,14 @@ struct StreamPhase {
     __device__ __forceinline__ void issue_a(Regs& x, int s) {
         if constexpr (SLOT) {
 #pragma unroll
-            for (int h = 0; h < AH; ++h) x.a[h] = ld16(p.A + aoff[h] + (long long)s * (KS * 2));
+            for (int h = 0; h < AH; ++h) x.a[h] = ld16g(p.A, aoff[h] + (long long)s * (KS * 2));
         }
     }
     __device__ __forceinline__ void issue(Regs& x) {
         const int s = wave + NW * ij;
         const long long koff = (long long)s * (KS * 2) + q * 32;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { x.w0[t] = ld16(wrow[t] + koff); x.w1[t] = ld16(wrow[t] + koff + 16); }
+        for (int t = 0; t < NT; ++t) { x.w0[t] = ld16g(wrow[t], koff); x.w1[t] = ld16g(wrow[t], koff + 16); }
         issue_a(x, s);
         ++ig;
         if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
@@ -147,9 +161,9 @@ struct StreamPhase {
 #pragma unroll
             for (int ri = 0; ri < NROW; ++ri) {
                 const int m = wave + 8 * ri < p.M ? wave + 8 * ri : p.M - 1;
-                sv[ri][j] = ld16(p.A + (long long)m * p.lda * 2 + cc * 16);
+                sv[ri][j] = ld16g(p.A, (long long)m * p.lda * 2 + cc * 16);
             }
-            if constexpr (AMODE == SKINNY_A_RMSNORM) sg[j] = ld16(p.norm_w + cc * 16);
+            if constexpr (AMODE == SKINNY_A_RMSNORM) sg[j] = ld16g(p.norm_w, cc * 16);
         }
     }
     __device__ __forceinline__ void stage_store(int c0) {
@@ -190,8 +204,8 @@ struct StreamPhase {
                 const int n = (u * NT + nt) * TR + (ln & 15), m = 4 * (ln >> 4) + reg;
                 const bool ok = o < NT * 256 && (ln & 15) < TR && n < p.N && m < p.M;
                 const int nc = ok ? n : 0, mc = ok ? m : 0;           // clamped: the loads are unconditional (no branch, no drain per element)
-                ep_b[i] = p.bias ? (float)reinterpret_cast<const bf16*>(p.bias)[nc] : 0.f;
-                ep_r[i] = p.res ? (float)*reinterpret_cast<const bf16*>(p.res + ((long long)mc * p.ldres + nc) * 2) : 0.f;
+                ep_b[i] = p.bias ? ld_bf16g(p.bias, (long long)nc * 2) : 0.f;
+                ep_r[i] = p.res ? ld_bf16g(p.res, ((long long)mc * p.ldres + nc) * 2) : 0.f;
             }
         }
     }
@@ -261,7 +275,7 @@ struct StreamPhase {
                         const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.norm_eps);
                         g *= rs; uu *= rs;
                     }
-                    reinterpret_cast<bf16*>(p.C)[(long long)mrow * p.ldc + gi] = (bf16)(silu(g) * uu);
+                    st_bf16g(p.C, ((long long)mrow * p.ldc + gi) * 2, silu(g) * uu);
                 }
             }
         } else {
@@ -279,12 +293,12 @@ struct StreamPhase {
                         if (p.bias) v += ep_b[i];
                         if (p.res) v += ep_r[i];
                         if (p.C) {
-                            if (p.out_f32) reinterpret_cast<float*>(p.C)[(long long)mm * p.ldc + nn] = v;
-                            else reinterpret_cast<bf16*>(p.C)[(long long)mm * p.ldc + nn] = (bf16)v;
+                            if (p.out_f32) st_f32g(p.C, ((long long)mm * p.ldc + nn) * 4, v);
+                            else st_bf16g(p.C, ((long long)mm * p.ldc + nn) * 2, v);
                         }
                         if (p.am_val) {
                             bool ok = false;
-                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= p.am_iv[2 * k] && nn < p.am_iv[2 * k + 1]);
+                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
                             const float vb = (float)(bf16)v;           // the reference takes argmax over model-dtype logits
                             if (ok && (vb > am_best || (vb == am_best && nn < am_bi))) { am_best = vb; am_bi = nn; }
                         }
@@ -372,8 +386,8 @@ struct StreamPhase {
                     const int i1 = am_i[(w0 + 4) * 4 + rg];
                     if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
                     const long long slot = (long long)tid * (int)gridDim.x + (int)blockIdx.x;
-                    p.am_val[slot] = b0;
-                    p.am_idx[slot] = i0;
+                    st_f32g(p.am_val, (long long)slot * 4, b0);
+                    st_f32g(p.am_idx, (long long)slot * 4, __int_as_float(i0));
                 }
             }
         }

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Compiles every HIP source of the library to assembly (device side only) and lists kernels whose metadata reports spilled vector registers
 (exit code 1) or a private segment without spills (a local array the kernel indexes at run time, or the emergency slot of spilled SCALAR
-registers: reported, not an error).  usage: python tools/check_spills.py [file.hip ...]"""
+registers: reported, not an error).  Also fails on any FLAT memory instruction: the library has no pointer that may be LDS or global, so a
+flat_load / flat_store means an address space got lost (an opaque `asm volatile("" : "+s"(ptr))` copy does that) -- round 4 found the decode
+GEMMs streaming their weights through flat loads (lgkmcnt waits of the LDS combine then drained the weight window) and the log-mel FFT reading
+its LDS tables through them.  usage: python tools/check_spills.py [file.hip ...]"""
 import glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "audio-intelligence_amd", "csrc")
@@ -24,5 +27,9 @@ for f in files:
             print(f"{base}: {name}: {sp} SPILLED VGPRs, {scratch} B scratch ({vg} VGPRs)")
         elif scratch:
             print(f"{base}: {name}: no spilled VGPRs; {scratch} B private segment ({vg} VGPRs)")
+    flat = len(re.findall(r"^\s+flat_(?:load|store|atomic)", txt, flags=re.M))
+    if flat:
+        bad += 1
+        print(f"{base}: {flat} FLAT memory instructions (an address space was lost)")
     print(f"{base}: {n} kernels checked")
 sys.exit(1 if bad else 0)
