@@ -565,12 +565,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 // load per range the merge of the 118 ranges of a 15 000-key context took 50 us per layer, longer than the attention itself.
 constexpr int CMB_CHUNK = 512;
 template <typename T>
-__global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
+__global__ void attn_combine_kernel(AttnP p_in, int n_split, int HD) {
+    // the arguments this launch reads, fetched in one batch (left alone the compiler spreads them over four dependent scalar round trips in a
+    // 5-us kernel); the opaque copy hides the address space of the pointers, the CMB_AS1 casts below put it back
+    AttnP p = p_in;
+    asm volatile("" : "+s"(p.o), "+s"(p.B), "+s"(p.Tq), "+s"(p.n_q), "+s"(p.ld_o), "+s"(p.o_bs), "+s"(p.o_hs), "+s"(p.scale_log2), "+s"(p.key_split),
+                 "+s"(p.part_o), "+s"(p.part_ml), "+s"(p.seq_pos), "+s"(p.o_img_rows), "+s"(n_split), "+s"(HD));
+#define CMB_AS1 __attribute__((address_space(1)))
+    const CMB_AS1 float* const part_ml = (const CMB_AS1 float*)p.part_ml;
+    const CMB_AS1 float* const part_o = (const CMB_AS1 float*)p.part_o;
     __shared__ float s_w[CMB_CHUNK], s_l[CMB_CHUNK], s_red[4];
     const int row = blockIdx.x;                      // (b, hq, qrow) flattened
     const int qrow = row % p.Tq, hq = (row / p.Tq) % p.n_q, b = row / (p.Tq * p.n_q);
     const int d = threadIdx.x;
-    if (p.seq_pos) { const int live = (p.seq_pos[b] + 1 + p.key_split - 1) / p.key_split; n_split = live < n_split ? live : n_split; }
+    if (p.seq_pos) { const int live = (((const CMB_AS1 int32_t*)p.seq_pos)[b] + 1 + p.key_split - 1) / p.key_split; n_split = live < n_split ? live : n_split; }
     auto slot_of = [&](int sp) { return (((long long)sp * p.B + b) * p.n_q + hq) * 32 + qrow; };
     if (n_split <= 16) {
         // short contexts (the 7B decode step: 7 key ranges of 128 keys, 14 of 64): every load of the merge -- the (max, sum) pairs and this thread's O column of
@@ -580,9 +588,9 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
 #pragma unroll
         for (int sp = 0; sp < 16; ++sp) {
             const long long slot = slot_of(sp < n_split ? sp : 0);
-            ms[sp] = p.part_ml[slot * 2];
-            ls[sp] = p.part_ml[slot * 2 + 1];
-            vs[sp] = p.part_o[slot * HD + d];
+            ms[sp] = part_ml[slot * 2];
+            ls[sp] = part_ml[slot * 2 + 1];
+            vs[sp] = part_o[slot * HD + d];
         }
         float m = -INFINITY;
 #pragma unroll
@@ -600,15 +608,15 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
         if (p.o_img_rows > 0) {
             const int RM = p.o_img_rows, k = (int)((long long)qrow * p.ld_o + (long long)hq * p.o_hs) + d;
             const long long off = (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + b) << 4) + ((k & 7) << 1);
-            *reinterpret_cast<T*>(p.o + off) = from_f32<T>(y);
+            *(CMB_AS1 T*)(p.o + off) = from_f32<T>(y);
         } else {
-            T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
+            CMB_AS1 T* op = (CMB_AS1 T*)p.o + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
             op[d] = from_f32<T>(y);
         }
         return;
     }
     float m = -INFINITY;
-    for (int sp = d; sp < n_split; sp += HD) m = fmaxf(m, p.part_ml[slot_of(sp) * 2]);
+    for (int sp = d; sp < n_split; sp += HD) m = fmaxf(m, part_ml[slot_of(sp) * 2]);
     m = wave_max(m);
     if ((d & 63) == 0) s_red[d >> 6] = m;
     __syncthreads();
@@ -620,30 +628,30 @@ __global__ void attn_combine_kernel(AttnP p, int n_split, int HD) {
         __syncthreads();                             // the previous chunk's weights have been consumed
         for (int i = d; i < n; i += HD) {
             const long long slot = slot_of(base + i);
-            const float ms = p.part_ml[slot * 2];
+            const float ms = part_ml[slot * 2];
             s_w[i] = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * p.scale_log2);
-            s_l[i] = p.part_ml[slot * 2 + 1];
+            s_l[i] = part_ml[slot * 2 + 1];
         }
         __syncthreads();
         int i = 0;
         for (; i + 8 <= n; i += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p.part_o[slot_of(base + i + u) * HD + d];
+            for (int u = 0; u < 8; ++u) v[u] = part_o[slot_of(base + i + u) * HD + d];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { l = fmaf(s_l[i + u], s_w[i + u], l); o = fmaf(v[u], s_w[i + u], o); }
         }
-        for (; i < n; ++i) { l = fmaf(s_l[i], s_w[i], l); o = fmaf(p.part_o[slot_of(base + i) * HD + d], s_w[i], o); }
+        for (; i < n; ++i) { l = fmaf(s_l[i], s_w[i], l); o = fmaf(part_o[slot_of(base + i) * HD + d], s_w[i], o); }
     }
     const float y = l > 0.f ? o / l : 0.f;
     if (p.o_img_rows > 0) {
         // element (row b, column k) of the image the decode step's o projection streams (img_phase.h)
         const int RM = p.o_img_rows, k = (int)((long long)qrow * p.ld_o + (long long)hq * p.o_hs) + d;
         const long long off = (long long)(k >> 6) * (RM * 128) + ((((k >> 3) & 1) * (4 * RM) + ((k >> 4) & 3) * RM + b) << 4) + ((k & 7) << 1);
-        *reinterpret_cast<T*>(p.o + off) = from_f32<T>(y);
+        *(CMB_AS1 T*)(p.o + off) = from_f32<T>(y);
         return;
     }
-    T* op = reinterpret_cast<T*>(p.o) + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
+    CMB_AS1 T* op = (CMB_AS1 T*)p.o + (long long)b * p.o_bs + (long long)qrow * p.ld_o + (long long)hq * p.o_hs;
     op[d] = from_f32<T>(y);
 }
 
