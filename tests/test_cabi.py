@@ -128,3 +128,16 @@ def test_log_mel_constant_tables_host():
         np.testing.assert_array_equal(cw[coff[m]: coff[m] + band[m, 1]], filt[band[m, 0]: band[m, 0] + band[m, 1], m])
     # (max, min) per clip and pass-1 workgroup (128 slots): the features themselves are written once, in place
     assert lib.afhip_log_mel_workspace_bytes(32) == 32 * 128 * 2 * 4
+
+
+def test_no_kernel_spills_and_no_flat_memory_instruction():
+    """tools/check_spills.py over every HIP source (device assembly only, no GPU needed): no kernel of the library spills vector registers,
+    and none contains a FLAT memory instruction -- the library has no pointer that may be LDS or global, so a flat_load means an address
+    space got lost on the way (round 4: the decode GEMMs streamed their weights through flat loads after an opaque scalar copy of their
+    arguments, and the log-mel FFT read its LDS tables through them)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_spills.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "kernels checked" in r.stdout
