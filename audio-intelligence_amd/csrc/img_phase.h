@@ -67,6 +67,8 @@ struct ImgPhase {
     int cu, cj;
     float am_best, ss_acc;
     int am_bi;
+    int am_lo[4], am_hi[4];              // the first four allowed-id intervals of the greedy pick, fetched once (load_am)
+    float pr_sg, pr_su;                  // e4m3 SwiGLU pair: the weight scales of this thread's gate / up row of the unit, fetched when the unit starts
 
     static constexpr size_t lds_bytes() { return (size_t)(2 * NW * NT * 256 + 16 + 64) * sizeof(float); }
 
@@ -128,6 +130,19 @@ struct ImgPhase {
         ++ig;
         if (++ij == spw) { ij = 0; ++iu; if (iu < my_units) set_rows(iu); }
     }
+    // e4m3 SwiGLU pair units: the two weight scales of this thread's output, fetched when the unit STARTS (read where they are used they were
+    // loads younger than the next unit's window, and their wait drained it at every unit's end)
+    __device__ __forceinline__ void fetch_pair(int ui) {
+        if constexpr (PAIR && W8) {
+            const int u = (int)blockIdx.x + ui * (int)gridDim.x;
+            const int ln = (tid >> 2) & 63;
+            int gi = u * TR + (ln & 15);
+            gi = (tid < 256 && (ln & 15) < TR && gi < gates) ? gi : 0;
+            const int ng = ((gi >> 5) << 6) + (gi & 31);
+            pr_sg = ld_f32g(p.w_scale, (long long)ng * 4);
+            pr_su = ld_f32g(p.w_scale, (long long)(ng + 32) * 4);
+        }
+    }
     // bias / residual / image gain of this thread's epilogue items (o = tid (+ 512): reg = o & 3, column = (o >> 2) & 15, row group =
     // (o >> 6) & 3, tile = o >> 8), fetched when a unit STARTS.
     __device__ __forceinline__ void fetch_epi(int ui) {
@@ -148,6 +163,17 @@ struct ImgPhase {
         }
     }
 
+    // The allowed-id intervals of the greedy pick (lm_head), BEFORE the weight window like the partial sums of squares: read per output element in
+    // the epilogue they were loads younger than the next unit's window, and vmcnt being in order their wait drained that window at every unit's end
+    // (ten times per workgroup in the lm_head).
+    __device__ __forceinline__ void load_am() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = p.am_val != nullptr && k < p.am_n_iv;
+            am_lo[k] = on ? ld_i32g(p.am_iv, (long long)(2 * k) * 4) : 0;
+            am_hi[k] = on ? ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4) : 0;           // [0, 0): matches nothing
+        }
+    }
     __device__ __forceinline__ void load_ss() {
 #pragma unroll
         for (int ri = 0; ri < RM / 8; ++ri) {
@@ -181,12 +207,13 @@ struct ImgPhase {
         // the partial sums of squares go out BEFORE the weight window: vmcnt retires in order, and behind the window their first use
         // drained all of it (gate/up: 5.8 us from launch to first MFMA, then a refill bubble)
         if constexpr (RMS) load_ss();
+        load_am();
         if (my_units > 0) set_rows(0);
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (ig < total) issue(r[d]);
         ST_STAMP(1);
-        if (my_units > 0) fetch_epi(0);
+        if (my_units > 0) { fetch_epi(0); fetch_pair(0); }
     }
 
     __device__ __forceinline__ void finish_unit() {
@@ -223,15 +250,13 @@ struct ImgPhase {
                         const float rs = rsqrtf(red_ss[mrow] / (float)p.K + p.eps);
                         g *= rs; uu *= rs;
                     }
-                    if constexpr (W8) {
-                        const int ng = ((gi >> 5) << 6) + (gi & 31);
-                        g *= ld_f32g(p.w_scale, (long long)ng * 4); uu *= ld_f32g(p.w_scale, (long long)(ng + 32) * 4);
-                    }
+                    if constexpr (W8) { g *= pr_sg; uu *= pr_su; }
                     const float y = silu(g) * uu;
                     if (p.img_out) st_bf16g(p.img_out, img_off(RM, mrow, gi), y);
                     else st_bf16g(p.C, ((long long)mrow * p.ldc + gi) * 2, y);
                 }
             }
+            if (cu + 1 < my_units) fetch_pair(cu + 1);
         } else {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -259,7 +284,9 @@ struct ImgPhase {
                         }
                         if (p.am_val) {
                             bool ok = false;
-                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
+                            #pragma unroll
+                            for (int k = 0; k < 4; ++k) ok = ok || (nn >= am_lo[k] && nn < am_hi[k]);
+                            for (int k = 4; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
                             const float vb = (float)(bf16)v;           // the reference takes argmax over model-dtype logits
                             if (ok && (vb > am_best || (vb == am_best && nn < am_bi))) { am_best = vb; am_bi = nn; }
                         }

@@ -95,6 +95,7 @@ struct StreamPhase {
     int cu, cj;
     float am_best;
     int am_bi;
+    int am_lo[4], am_hi[4];              // the first four allowed-id intervals of the greedy pick, fetched once in begin()
 
     static constexpr size_t fixed_lds() { return (size_t)(2 * NW * NT * 256 + 16 + 64) * sizeof(float); }
     static size_t lds_bytes(int K) { return fixed_lds() + (SLOT ? (size_t)NW * DEPTH * RM * 128 : (size_t)RM * K * 2); }
@@ -240,6 +241,13 @@ struct StreamPhase {
 #pragma unroll
         for (int ri = 0; ri < NROW; ++ri) ssq[ri] = 0.f;
         ig = 0; iu = 0; ij = 0;
+        // the allowed-id intervals of the greedy pick, once and before the window (img_phase.h: load_am)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = p.am_val != nullptr && k < p.am_n_iv;
+            am_lo[k] = on ? ld_i32g(p.am_iv, (long long)(2 * k) * 4) : 0;
+            am_hi[k] = on ? ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4) : 0;
+        }
         // the staging loads go out BEFORE the weight window (vmcnt retires in order: behind the weights they would wait for HBM)
         if constexpr (!SLOT) stage_load(0);
         if (my_units > 0) set_rows(0);
@@ -298,7 +306,9 @@ struct StreamPhase {
                         }
                         if (p.am_val) {
                             bool ok = false;
-                            for (int k = 0; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
+                            #pragma unroll
+                            for (int k = 0; k < 4; ++k) ok = ok || (nn >= am_lo[k] && nn < am_hi[k]);
+                            for (int k = 4; k < p.am_n_iv; ++k) ok = ok || (nn >= ld_i32g(p.am_iv, (long long)(2 * k) * 4) && nn < ld_i32g(p.am_iv, (long long)(2 * k + 1) * 4));
                             const float vb = (float)(bf16)v;           // the reference takes argmax over model-dtype logits
                             if (ok && (vb > am_best || (vb == am_best && nn < am_bi))) { am_best = vb; am_bi = nn; }
                         }
