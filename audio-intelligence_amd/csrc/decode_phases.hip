@@ -136,6 +136,12 @@ __global__ __launch_bounds__(512) void pick_kernel(PickArgs k) { pick_phase(k); 
 #ifndef DP_DEPTH_GU
 #define DP_DEPTH_GU 4
 #endif
+#ifndef DP_HEAD_NT
+#define DP_HEAD_NT 4          // lm_head: tiles of 16 vocabulary rows per unit
+#endif
+#ifndef DP_HEAD_DEPTH
+#define DP_HEAD_DEPTH 2
+#endif
 // ... and of the e4m3-weight phases (a K step is 128 elements there)
 #ifndef DP8_DEPTH_O
 #define DP8_DEPTH_O 7
@@ -172,7 +178,7 @@ template <int RM> void launch_single(const PhaseArgs& a, int cus, hipStream_t s)
         case AFHIP_PH_GU: launch_phase<ImgPhase<2, true, true, RM, DP_DEPTH_GU>>(a.gu, cus, s); break;
         case AFHIP_PH_DOWN: launch_phase<ImgPhase<1, false, false, RM, DP_DEPTH_DOWN>>(a.down, cus, s); break;
         case AFHIP_PH_QKV: launch_phase<ImgPhase<2, false, true, RM, DP_DEPTH_QKV>>(a.qkv, cus, s); break;
-        case AFHIP_PH_HEAD: launch_phase<ImgPhase<4, false, true, RM, 2>>(a.head, cus, s); break;
+        case AFHIP_PH_HEAD: launch_phase<ImgPhase<DP_HEAD_NT, false, true, RM, DP_HEAD_DEPTH>>(a.head, cus, s); break;
         default: hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(512), 0, s, a.pick); break;
     }
 }
