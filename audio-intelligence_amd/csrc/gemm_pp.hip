@@ -52,11 +52,12 @@ constexpr int PP_HALF = 16384;           // 128 rows x 128 B
 constexpr int PP_STAGE = 4 * PP_HALF;    // A0 A1 B0 B1
 constexpr int PP_OFF_A0 = 0, PP_OFF_A1 = PP_HALF, PP_OFF_B0 = 2 * PP_HALF, PP_OFF_B1 = 3 * PP_HALF;
 constexpr int PP_LDS = 2 * PP_STAGE;     // 128 KiB
-#ifdef AFHIP_PP_STAMPS   /* diagnostic build: -DAFHIP_PP_STAMPS, tools/gemm_stamps.py (never the product library) */
-constexpr int PP_LDS_TOTAL = PP_LDS;
-#else
-constexpr int PP_LDS_TOTAL = PP_LDS;
-#endif
+// LayerNorm-folded forms: the epilogue's operands of a tile -- colsum[256] | bias'[256] | (mean, rstd)[256] = 4 KiB -- are fetched by ONE
+// LDS-DMA instruction per wave at the top of the tile's last K-tile pair and read back with ds_read in the epilogue.  Loaded where they
+// are used (round 1-3) they were 16 global loads per lane issued BEHIND the run-ahead operand stream, and the epilogue stood still for
+// one memory latency per tile: 6-7 % of the q | k | v and fc1 launches (timing build, round 4).  Two areas, by tile parity.
+constexpr int PP_EPI = 4096;
+constexpr int PP_LDS_TOTAL = PP_LDS + 2 * PP_EPI;
 
 struct PPArgs {
     const char* A;
@@ -145,6 +146,7 @@ __device__ __forceinline__ void pp_dma_half(const char* base, unsigned nrec, int
 // counted wait of the LOAD sections of phases 3, 0, 1: the half-tile read in the NEXT phase has landed, younger ones stay in flight.
 // DMA in the LOAD section: issued so far includes this phase's -> 4 half-tiles (8 instructions) younger; DMA in the MFMA section:
 // this phase's is not issued yet -> 3 half-tiles (6 instructions) younger.
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 #define PP_WAIT_VM() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define PP_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define PP_WAIT_VM10() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
@@ -314,8 +316,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     typedef std::integral_constant<int, 1> I1;
 
     // one K tile in stage S
-    auto ktile = [&](auto s_tag) {
+    // XTRA: vector-memory instructions issued just before this K tile that are NOT part of the operand stream (the epilogue operands'
+    // DMA): they sit in the in-order queue between the stream's older and newer half-tiles, so every counted wait of THIS K tile allows
+    // that many more outstanding; from the next K tile on the awaited half-tiles are younger than they are and the counts are the usual ones
+    auto ktile = [&](auto s_tag, auto x_tag) {
         constexpr int S = decltype(s_tag)::value;
+        constexpr int XTRA = decltype(x_tag)::value;
         const char* st = smem + S * PP_STAGE;
         char* d_same = dma_dst + S * PP_STAGE;
         char* d_other = dma_dst + (S ^ 1) * PP_STAGE;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             read_a(st + PP_OFF_A0);
         }
         dma0();
-        PP_WAIT_VM();
+        pp_wait_vm<8 + XTRA>();
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         // phase 1
         read_b(st + PP_OFF_B1, fb1);
         dma1();
-        PP_WAIT_VM();
+        pp_wait_vm<8 + XTRA>();
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
         // phase 2
         read_a(st + PP_OFF_A1);
         dma2();
-        if constexpr (EARLY_A0) PP_WAIT_VM8();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
+        if constexpr (EARLY_A0) pp_wait_vm<8 + XTRA>();   // A0 of the next tile has landed one phase early (it has the slack: issued 5 phases ago)
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             for (int i = 0; i < 4; ++i) fa0k0[i] = *reinterpret_cast<const bf16x8*>(smem + (S ^ 1) * PP_STAGE + PP_OFF_A0 + aoff0 + i * 2048);
         }
         dma3();
-        PP_WAIT_VM();
+        pp_wait_vm<8 + XTRA>();
         PP_STAMP();
         PP_BARRIER();
         PP_STAMP();
@@ -384,15 +390,37 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
     };
 
     for (int it = 0; it < n_my; ++it) {
-        for (int k2 = 0; k2 < nk2; ++k2) {
+        for (int k2 = 0; k2 < nk2 - (LNFOLD ? 1 : 0); ++k2) {
 #ifdef AFHIP_PP_STAMPS
             st_on = st_wave && it == 1 && k2 == 4;
 #endif
-            ktile(I0{});
+            ktile(I0{}, I0{});
 #ifdef AFHIP_PP_STAMPS
             st_on = false;
 #endif
-            ktile(I1{});
+            ktile(I1{}, I0{});
+        }
+        if constexpr (LNFOLD) {
+            // the tile's last K-tile pair, with the epilogue operands' DMA in front of it: wave w (and w + 4, same bytes) fetches piece w & 3
+            // -- colsum, bias', (mean, rstd) of rows 0..127, of rows 128..255; rows past M are out of the descriptor's range and read 0
+            int m0e, n0e;
+            pp_tile_coords(p, (int)blockIdx.x + it * (int)gridDim.x, m0e, n0e);
+            const int piece = wave & 3;
+            const char* ebase;
+            int enrec;
+            if (piece == 0) { ebase = reinterpret_cast<const char*>(p.ln_colsum + n0e); enrec = 1024; }
+            else if (piece == 1) { ebase = reinterpret_cast<const char*>(p.ln_bias + n0e); enrec = 1024; }
+            else {
+                const int r0 = m0e + (piece - 2) * 128;
+                int rows = p.M - r0;
+                rows = rows < 0 ? 0 : (rows > 128 ? 128 : rows);
+                ebase = reinterpret_cast<const char*>(p.ln_stats + 2 * (long long)(rows > 0 ? r0 : 0));
+                enrec = rows * 8;
+            }
+            __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc((void*)ebase, 0, enrec, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(er, (lds_ptr_t)(smem + PP_LDS + (it & 1) * PP_EPI + piece * 1024), 16, lane * 16, 0, 0, 0);
+            ktile(I0{}, I1{});
+            ktile(I1{}, I0{});
         }
 #ifdef AFHIP_PP_STAMPS
         st_on = st_wave && it == 1;
@@ -451,8 +479,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             if constexpr (LNFOLD) {
                 // LayerNorm folded into this GEMM: A is the raw residual stream, W' = W diag(gamma), and
                 //   LN(x) W^T + b = rstd[m] (x W'^T - mean[m] colsum[n]) + (b + W beta)[n]
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + hb * 32), c1 = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + hb * 32 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_bias + ncol + hb * 32), b1 = *reinterpret_cast<const f32x4*>(p.ln_bias + ncol + hb * 32 + 4);
+                // from the tile's LDS area (fetched two K tiles ago; the last K tile's first wait and its barriers made it complete and visible)
+                const float* ef = reinterpret_cast<const float*>(smem + PP_LDS + (it & 1) * PP_EPI) + wn * 64 + q4 * 8 + hb * 32;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ef), c1 = *reinterpret_cast<const f32x4*>(ef + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ef + 256), b1 = *reinterpret_cast<const f32x4*>(ef + 260);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cv[hb][e] = c0[e]; cv[hb][4 + e] = c1[e]; bv[hb][e] = b0[e]; bv[hb][4 + e] = b1[e]; }
             } else if constexpr (HAS_BIAS) {
@@ -485,9 +515,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs p) {
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int m = m0 + grp * 128 + ha * 64 + i * 16 + c16;
-                    m = m < p.M ? m : p.M - 1;
-                    st2[ha][i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)m);
+                    st2[ha][i] = *reinterpret_cast<const f32x2*>(smem + PP_LDS + (it & 1) * PP_EPI + 2048 + (grp * 128 + ha * 64 + i * 16 + c16) * 8);
                 }
         }
         PP_STAMP();                               // 41: epilogue operand loads issued
